@@ -1,0 +1,688 @@
+"""ORACLE (test infrastructure, NOT product code) -- CPU restatement of the Equiformer hot path.
+
+PARITY UNPINNED (see oracle/e3.py header): the reference cannot be imported here and holds no golden vectors.
+Op-for-op restatement, in plain torch (fp32 or fp64, CPU), of the model classes of the reference
+(paths relative to /root/reference):
+
+  nets/graph_attention_transformer.py      SmoothLeakyReLU :54-63, DepthwiseTensorProduct :157-183, SeparableFCTP :186-248,
+                                           Vec2AttnHeads :251-280, AttnHeads2Vec :288-312, GraphAttention :403-527,
+                                           FeedForwardNetwork :537-571, TransBlock :575-667, NodeEmbeddingNetwork :670-690,
+                                           ScaledScatter :693-702, EdgeDegreeEmbeddingNetwork :709-733,
+                                           GraphAttentionTransformer :736-899, factories :902-937
+  nets/tensor_product_rescale.py           TensorProductRescale :15-141, FullyConnectedTensorProductRescale :144-162,
+                                           LinearRS :165-174, irreps2gate :177-192
+  nets/layer_norm.py                       EquivariantLayerNormV2 :62-152
+  nets/fast_activation.py                  Activation :15-87, Gate :91-160
+  nets/radial_func.py                      RadialProfile :9-49
+  nets/gaussian_rbf.py                     gaussian :5-9, GaussianRadialBasisLayer :13-40
+  nets/graph_attention_transformer_md17.py CosineCutoff :51-81, ExpNormalSmearing :85-124, model :127-327, factories :407-442
+  nets/graph_attention_transformer_oc20.py energy path of GraphAttentionTransformerOC20 :85-381 (non-PBC / precomputed-edge form)
+
+Third-party ops restated: torch_cluster.radius_graph (1.6.0), torch_scatter.scatter (2.0.9),
+torch_geometric.utils.softmax / nn.inits.glorot (2.0.3).
+Module / parameter names equal the reference's so that state_dicts are interchangeable with the product
+package (`equiformer_amd.nets`).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .e3 import Irrep, Irreps, TensorProduct, normalize2mom_const, sort_irreps_even_first, spherical_harmonics
+
+_RESCALE = True
+_USE_BIAS = True
+
+
+# ---------------------------------------------------------------------------- third-party graph ops
+def radius_graph(pos, r, batch, max_num_neighbors=1000):
+    """torch_cluster.radius_graph(flow='source_to_target', loop=False): returns (edge_src=neighbour,
+    edge_dst=centre), grouped by ascending dst then ascending src, strict d < r, same molecule only."""
+    n = pos.shape[0]
+    d2 = (pos[:, None, :] - pos[None, :, :]).pow(2).sum(-1)
+    same = batch[:, None] == batch[None, :]
+    adj = same & (d2 < r * r) & ~torch.eye(n, dtype=torch.bool, device=pos.device)
+    dst, src = adj.nonzero(as_tuple=True)  # row-major nonzero: dst ascending, src ascending
+    if max_num_neighbors is not None:
+        # keep the first max_num_neighbors sources per destination (torch_cluster visits sources in index order)
+        rank = torch.cumsum(adj.long(), dim=1)[dst, src]
+        keep = rank <= max_num_neighbors
+        dst, src = dst[keep], src[keep]
+    return src, dst
+
+
+def scatter_sum(x, index, dim_size):
+    out = x.new_zeros((dim_size,) + x.shape[1:])
+    return out.index_add(0, index, x)
+
+
+def segment_softmax(src, index, num_nodes):
+    """torch_geometric.utils.softmax (2.0.3): exp(x - max_seg) / (sum_seg + 1e-16)."""
+    smax = src.new_full((num_nodes,) + src.shape[1:], float("-inf"))
+    smax = smax.scatter_reduce(0, index.view(-1, *([1] * (src.dim() - 1))).expand_as(src), src, reduce="amax")
+    out = (src - smax[index]).exp()
+    ssum = scatter_sum(out, index, num_nodes)
+    return out / (ssum[index] + 1e-16)
+
+
+# ---------------------------------------------------------------------------- tensor_product_rescale.py
+class TensorProductRescale(nn.Module):
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, instructions, bias=True, rescale=True,
+                 internal_weights=None, shared_weights=None):
+        super().__init__()
+        self.irreps_in1, self.irreps_in2, self.irreps_out = Irreps(irreps_in1), Irreps(irreps_in2), Irreps(irreps_out)
+        self.rescale, self.use_bias = rescale, bias
+        self.tp = TensorProduct(self.irreps_in1, self.irreps_in2, self.irreps_out, instructions,
+                                internal_weights=internal_weights, shared_weights=shared_weights)
+        # bias on every 0e slice of the *simplified* output irreps (:55-83)
+        self.irreps_bias = self.irreps_out.simplify()
+        self.bias_slices = []
+        biases = []
+        if bias:
+            for (mul, ir), sl in zip(self.irreps_bias, self.irreps_bias.slices()):
+                if ir.l == 0 and ir.p == 1:
+                    biases.append(nn.Parameter(torch.zeros(mul)))
+                    self.bias_slices.append(sl)
+        self.bias = nn.ParameterList(biases)
+        # fan-in per output slice (:85-110)
+        fan = {}
+        for i1, i2, io, mode, _, _ in self.tp.instructions:
+            m1, m2 = self.irreps_in1[i1][0], self.irreps_in2[i2][0]
+            f = {"uvw": m1 * m2, "uvu": m2, "uuu": 1}[mode]
+            fan[io] = fan.get(io, 0) + f
+        out_slices = self.irreps_out.slices()
+        self.slices_sqrt_k = {io: (out_slices[io], 1 / fan[io] ** 0.5 if rescale else 1.0) for io in fan}
+        if self.tp.internal_weights and rescale:
+            with torch.no_grad():
+                for w, ins in zip(self.tp.weight_views(), [i for i in self.tp.instructions if i[4]]):
+                    w.mul_(self.slices_sqrt_k[ins[2]][1])  # views alias tp.weight storage
+
+    def forward(self, x, y, weight=None):
+        out = self.tp(x, y, weight)
+        for sl, b in zip(self.bias_slices, self.bias):
+            out = torch.cat([out[:, :sl.start], out[:, sl] + b, out[:, sl.stop:]], dim=1)
+        return out
+
+
+class FullyConnectedTensorProductRescale(TensorProductRescale):
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, bias=True, rescale=True, internal_weights=None,
+                 shared_weights=None):
+        irreps_in1, irreps_in2, irreps_out = Irreps(irreps_in1), Irreps(irreps_in2), Irreps(irreps_out)
+        ins = [(i1, i2, io, "uvw", True, 1.0)
+               for i1, (_, a) in enumerate(irreps_in1) for i2, (_, b) in enumerate(irreps_in2)
+               for io, (_, c) in enumerate(irreps_out) if c in a * b]
+        super().__init__(irreps_in1, irreps_in2, irreps_out, ins, bias=bias, rescale=rescale,
+                         internal_weights=internal_weights, shared_weights=shared_weights)
+
+
+class LinearRS(FullyConnectedTensorProductRescale):
+    def __init__(self, irreps_in, irreps_out, bias=True, rescale=True):
+        super().__init__(irreps_in, Irreps("1x0e"), irreps_out, bias=bias, rescale=rescale,
+                         internal_weights=True, shared_weights=True)
+
+    def forward(self, x):
+        return super().forward(x, torch.ones_like(x[:, 0:1]))
+
+
+def irreps2gate(irreps):
+    scalars = Irreps([(m, ir) for m, ir in Irreps(irreps) if ir.l == 0 and ir.p == 1]).simplify()
+    gated = Irreps([(m, ir) for m, ir in Irreps(irreps) if not (ir.l == 0 and ir.p == 1)]).simplify()
+    gates = Irreps([(m, "0e") for m, _ in gated]).simplify() if gated.dim > 0 else Irreps()
+    return scalars, gates, gated
+
+
+# ---------------------------------------------------------------------------- fast_activation.py
+class ScaledAct(nn.Module):
+    """normalize2mom(act): act(x) * c, c from the e3nn Monte-Carlo recipe."""
+
+    def __init__(self, act):
+        super().__init__()
+        self.act = act
+        self.cst = normalize2mom_const(act)
+
+    def forward(self, x):
+        return self.act(x) * self.cst
+
+
+class SmoothLeakyReLU(nn.Module):
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.alpha = negative_slope
+
+    def forward(self, x):
+        return ((1 + self.alpha) / 2) * x + ((1 - self.alpha) / 2) * x * (2 * torch.sigmoid(x) - 1)
+
+
+class Activation(nn.Module):
+    """Single-act form only (all call sites in the hot path): applied to the whole tensor (:70-71)."""
+
+    def __init__(self, irreps_in, acts):
+        super().__init__()
+        self.irreps_in = self.irreps_out = Irreps(irreps_in)
+        assert len(acts) == 1 and len(self.irreps_in) == 1 and self.irreps_in[0][1].l == 0
+        self.acts = nn.ModuleList([ScaledAct(acts[0])])
+
+    def forward(self, x):
+        return self.acts[0](x)
+
+
+class Gate(nn.Module):
+    def __init__(self, irreps_scalars, irreps_gates, irreps_gated):
+        super().__init__()
+        self.irreps_scalars, self.irreps_gates, self.irreps_gated = irreps_scalars, irreps_gates, irreps_gated
+        self.irreps_in = (irreps_scalars + irreps_gates + irreps_gated).simplify()
+        self.irreps_out = irreps_scalars + irreps_gated
+        self.act_scalars = ScaledAct(torch.nn.functional.silu)
+        self.act_gates = ScaledAct(torch.sigmoid)
+
+    def forward(self, x):
+        ns, ng = self.irreps_scalars.dim, self.irreps_gates.dim
+        scalars, gates, gated = x[:, :ns], x[:, ns:ns + ng], x[:, ns + ng:]
+        scalars, gates = self.act_scalars(scalars), self.act_gates(gates)
+        out, ig, ix = [scalars], 0, 0
+        for mul, ir in self.irreps_gated:  # o3.ElementwiseTensorProduct(gated, gates): 'uuu', C(l,0,l) -> plain product
+            blk = gated[:, ix:ix + mul * ir.dim].reshape(-1, mul, ir.dim) * gates[:, ig:ig + mul, None]
+            out.append(blk.reshape(-1, mul * ir.dim))
+            ig, ix = ig + mul, ix + mul * ir.dim
+        return torch.cat(out, dim=1)
+
+
+def make_gate(irreps_out):
+    scalars, gates, gated = irreps2gate(irreps_out)
+    if gated.num_irreps == 0:
+        return Activation(irreps_out, [torch.nn.functional.silu])
+    return Gate(scalars, gates, gated)
+
+
+# ---------------------------------------------------------------------------- layer_norm.py / radial_func.py / rbf
+class EquivariantLayerNormV2(nn.Module):
+    def __init__(self, irreps, eps=1e-5):
+        super().__init__()
+        self.irreps, self.eps = Irreps(irreps), eps
+        self.affine_weight = nn.Parameter(torch.ones(self.irreps.num_irreps))
+        self.affine_bias = nn.Parameter(torch.zeros(sum(m for m, ir in self.irreps if ir.l == 0 and ir.p == 1)))
+
+    def forward(self, x, **kwargs):
+        out, ix, iw, ib = [], 0, 0, 0
+        for mul, ir in self.irreps:
+            f = x[:, ix:ix + mul * ir.dim].reshape(-1, mul, ir.dim)
+            ix += mul * ir.dim
+            if ir.l == 0 and ir.p == 1:
+                f = f - f.mean(dim=1, keepdim=True)
+            nrm = f.pow(2).mean(-1).mean(dim=1, keepdim=True)
+            nrm = (nrm + self.eps).pow(-0.5) * self.affine_weight[None, iw:iw + mul]
+            iw += mul
+            f = f * nrm.reshape(-1, mul, 1)
+            if ir.dim == 1 and ir.p == 1:
+                f = f + self.affine_bias[ib:ib + mul].reshape(mul, 1)
+                ib += mul
+            out.append(f.reshape(-1, mul * ir.dim))
+        assert ix == x.shape[-1]
+        return torch.cat(out, dim=-1)
+
+
+class RadialProfile(nn.Module):
+    def __init__(self, ch_list):
+        super().__init__()
+        mods = []
+        for i in range(1, len(ch_list)):
+            last = i == len(ch_list) - 1
+            mods.append(nn.Linear(ch_list[i - 1], ch_list[i], bias=not last))
+            if last:
+                break
+            mods += [nn.LayerNorm(ch_list[i]), nn.SiLU()]
+        self.net = nn.Sequential(*mods)
+        self.offset = nn.Parameter(torch.zeros(ch_list[-1]))
+        bound = 1 / math.sqrt(ch_list[-2])
+        nn.init.uniform_(self.offset, -bound, bound)
+
+    def forward(self, x):
+        return self.net(x) + self.offset.reshape(1, -1)
+
+
+class GaussianRadialBasisLayer(nn.Module):
+    def __init__(self, num_basis, cutoff):
+        super().__init__()
+        self.num_basis, self.cutoff = num_basis, cutoff + 0.0
+        self.mean = nn.Parameter(torch.zeros(1, num_basis))
+        self.std = nn.Parameter(torch.zeros(1, num_basis))
+        self.weight = nn.Parameter(torch.ones(1, 1))
+        self.bias = nn.Parameter(torch.zeros(1, 1))
+        nn.init.uniform_(self.mean, 0, 1.0)
+        nn.init.uniform_(self.std, 1.0 / num_basis, 1.0)
+
+    def forward(self, dist, *unused):
+        x = self.weight * (dist / self.cutoff).unsqueeze(-1) + self.bias
+        std = self.std.abs() + 1e-5
+        a = (2 * 3.14159) ** 0.5  # sic: truncated pi (gaussian_rbf.py:6)
+        return torch.exp(-0.5 * ((x - self.mean) / std) ** 2) / (a * std)
+
+
+class ExpNormalSmearing(nn.Module):
+    def __init__(self, cutoff_lower=0.0, cutoff_upper=5.0, num_rbf=50):
+        super().__init__()
+        self.cutoff_lower, self.cutoff_upper = cutoff_lower, cutoff_upper
+        self.alpha = 5.0 / (cutoff_upper - cutoff_lower)
+        start = torch.exp(torch.scalar_tensor(-cutoff_upper + cutoff_lower))
+        self.register_buffer("means", torch.linspace(start, 1, num_rbf))
+        self.register_buffer("betas", torch.tensor([(2 / num_rbf * (1 - start)) ** -2] * num_rbf))
+
+    def forward(self, dist):
+        d = dist.unsqueeze(-1)
+        cut = 0.5 * (torch.cos(d * math.pi / self.cutoff_upper) + 1.0) * (d < self.cutoff_upper).to(d.dtype)
+        return cut * torch.exp(-self.betas * (torch.exp(self.alpha * (-d + self.cutoff_lower)) - self.means) ** 2)
+
+
+# ---------------------------------------------------------------------------- graph_attention_transformer.py
+def DepthwiseTensorProduct(irreps_in, irreps_edge, irreps_node_output, internal_weights=False, bias=True):
+    irreps_in, irreps_edge, irreps_node_output = Irreps(irreps_in), Irreps(irreps_edge), Irreps(irreps_node_output)
+    out, ins = [], []
+    for i, (mul, ir_in) in enumerate(irreps_in):
+        for j, (_, ir_e) in enumerate(irreps_edge):
+            for ir_out in ir_in * ir_e:
+                if ir_out in irreps_node_output or ir_out == Irrep(0, 1):
+                    ins.append((i, j, len(out), "uvu", True))
+                    out.append((mul, ir_out))
+    out, p, _ = sort_irreps_even_first(Irreps(out))
+    ins = [(a, b, p[c], m, t) for a, b, c, m, t in ins]
+    return TensorProductRescale(irreps_in, irreps_edge, out, ins, internal_weights=internal_weights,
+                                shared_weights=internal_weights, bias=bias, rescale=_RESCALE)
+
+
+class SeparableFCTP(nn.Module):
+    def __init__(self, irreps_in, irreps_edge, irreps_out, fc_neurons, use_activation=False, internal_weights=False):
+        super().__init__()
+        irreps_out = Irreps(irreps_out)
+        self.dtp = DepthwiseTensorProduct(irreps_in, irreps_edge, irreps_out, bias=False,
+                                          internal_weights=internal_weights)
+        self.dtp_rad = None
+        if fc_neurons is not None:
+            self.dtp_rad = RadialProfile(fc_neurons + [self.dtp.tp.weight_numel])
+            for sl, k in self.dtp.slices_sqrt_k.values():  # k == 1 for 'uvu' with mul2 == 1
+                self.dtp_rad.net[-1].weight.data[sl, :] *= k
+                self.dtp_rad.offset.data[sl] *= k
+        lin_out = irreps_out
+        if use_activation:
+            s, g, gd = irreps2gate(irreps_out)
+            lin_out = (s + g + gd).simplify()
+        self.lin = LinearRS(self.dtp.irreps_out.simplify(), lin_out)
+        self.gate = make_gate(irreps_out) if use_activation else None
+
+    def forward(self, x, edge_attr, edge_scalars):
+        w = self.dtp_rad(edge_scalars) if (self.dtp_rad is not None and edge_scalars is not None) else None
+        out = self.lin(self.dtp(x, edge_attr, w))
+        return self.gate(out) if self.gate is not None else out
+
+
+def vec2heads(x, irreps_head, num_heads):
+    out, ix = [], 0
+    for mul, ir in irreps_head:
+        w = num_heads * mul * ir.dim
+        out.append(x[:, ix:ix + w].reshape(x.shape[0], num_heads, -1))
+        ix += w
+    return torch.cat(out, dim=2)
+
+
+def heads2vec(x, irreps_head):
+    out, ix = [], 0
+    for mul, ir in irreps_head:
+        w = mul * ir.dim
+        out.append(x[:, :, ix:ix + w].reshape(x.shape[0], -1))
+        ix += w
+    return torch.cat(out, dim=1)
+
+
+class GraphAttention(nn.Module):
+    def __init__(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_output, fc_neurons,
+                 irreps_head, num_heads, irreps_pre_attn=None, rescale_degree=False, nonlinear_message=False,
+                 alpha_drop=0.1, proj_drop=0.1):
+        super().__init__()
+        self.irreps_node_input = Irreps(irreps_node_input)
+        self.irreps_pre_attn = self.irreps_node_input if irreps_pre_attn is None else Irreps(irreps_pre_attn)
+        self.irreps_head, self.num_heads = Irreps(irreps_head), num_heads
+        self.rescale_degree, self.nonlinear_message = rescale_degree, nonlinear_message
+        self.merge_src = LinearRS(self.irreps_node_input, self.irreps_pre_attn, bias=True)
+        self.merge_dst = LinearRS(self.irreps_node_input, self.irreps_pre_attn, bias=False)
+        heads_all = sort_irreps_even_first(self.irreps_head * num_heads)[0].simplify()
+        mul_alpha = sum(m for m, ir in heads_all if ir.l == 0 and ir.p == 1)
+        self.mul_alpha_head = mul_alpha // num_heads
+        irreps_alpha = Irreps("{}x0e".format(mul_alpha))
+        self.irreps_alpha_head = Irreps("{}x0e".format(self.mul_alpha_head))
+        if nonlinear_message:
+            self.sep_act = SeparableFCTP(self.irreps_pre_attn, irreps_edge_attr, self.irreps_pre_attn, fc_neurons,
+                                         use_activation=True, internal_weights=False)
+            self.sep_alpha = LinearRS(self.sep_act.dtp.irreps_out, irreps_alpha)
+            self.sep_value = SeparableFCTP(self.irreps_pre_attn, irreps_edge_attr, heads_all, fc_neurons=None,
+                                           use_activation=False, internal_weights=True)
+        else:
+            self.sep = SeparableFCTP(self.irreps_pre_attn, irreps_edge_attr, (irreps_alpha + heads_all).simplify(),
+                                     fc_neurons, use_activation=False)
+            self.irreps_mix_head = (self.irreps_alpha_head + self.irreps_head).simplify()
+        self.alpha_act = Activation(self.irreps_alpha_head, [SmoothLeakyReLU(0.2)])
+        self.alpha_dot = nn.Parameter(torch.randn(1, num_heads, self.mul_alpha_head))
+        stdv = math.sqrt(6.0 / (self.alpha_dot.size(-2) + self.alpha_dot.size(-1)))  # PyG glorot
+        self.alpha_dot.data.uniform_(-stdv, stdv)
+        self.alpha_dropout = nn.Dropout(alpha_drop) if alpha_drop != 0.0 else None
+        self.proj = LinearRS(heads_all, Irreps(irreps_node_output))
+        assert proj_drop == 0.0
+
+    def forward(self, node_input, edge_src, edge_dst, edge_attr, edge_scalars):
+        message = self.merge_src(node_input)[edge_src] + self.merge_dst(node_input)[edge_dst]
+        if self.nonlinear_message:
+            weight = self.sep_act.dtp_rad(edge_scalars)
+            message = self.sep_act.dtp(message, edge_attr, weight)
+            alpha = vec2heads(self.sep_alpha(message), self.irreps_alpha_head, self.num_heads)
+            value = self.sep_act.gate(self.sep_act.lin(message))
+            value = self.sep_value(value, edge_attr, edge_scalars)
+            value = vec2heads(value, self.irreps_head, self.num_heads)
+        else:
+            message = vec2heads(self.sep(message, edge_attr, edge_scalars), self.irreps_mix_head, self.num_heads)
+            alpha, value = message[:, :, :self.mul_alpha_head], message[:, :, self.mul_alpha_head:]
+        alpha = self.alpha_act(alpha)
+        alpha = torch.einsum("bik,aik->bi", alpha, self.alpha_dot)
+        alpha = segment_softmax(alpha, edge_dst, node_input.shape[0]).unsqueeze(-1)
+        if self.alpha_dropout is not None:
+            alpha = self.alpha_dropout(alpha)
+        attn = heads2vec(scatter_sum(value * alpha, edge_dst, node_input.shape[0]), self.irreps_head)
+        if self.rescale_degree:
+            deg = scatter_sum(torch.ones_like(edge_dst, dtype=attn.dtype), edge_dst, node_input.shape[0])
+            attn = attn * deg.view(-1, 1)
+        return self.proj(attn)
+
+
+class FCTPSwishGate(FullyConnectedTensorProductRescale):
+    """FullyConnectedTensorProductRescaleSwishGate (graph_attention_transformer.py:128-154)."""
+
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, bias=True, rescale=True):
+        gate = make_gate(irreps_out)
+        super().__init__(irreps_in1, irreps_in2, gate.irreps_in, bias=bias, rescale=rescale)
+        self.gate = gate
+
+    def forward(self, x, y, weight=None):
+        return self.gate(super().forward(x, y, weight))
+
+
+class FeedForwardNetwork(nn.Module):
+    def __init__(self, irreps_node_input, irreps_node_attr, irreps_node_output, irreps_mlp_mid=None, proj_drop=0.0):
+        super().__init__()
+        mid = Irreps(irreps_mlp_mid) if irreps_mlp_mid is not None else Irreps(irreps_node_input)
+        self.fctp_1 = FCTPSwishGate(irreps_node_input, irreps_node_attr, mid, bias=True, rescale=_RESCALE)
+        self.fctp_2 = FullyConnectedTensorProductRescale(mid, irreps_node_attr, irreps_node_output, bias=True,
+                                                         rescale=_RESCALE)
+        assert proj_drop == 0.0
+
+    def forward(self, x, node_attr):
+        return self.fctp_2(self.fctp_1(x, node_attr), node_attr)
+
+
+class TransBlock(nn.Module):
+    def __init__(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_output, fc_neurons,
+                 irreps_head, num_heads, irreps_pre_attn=None, rescale_degree=False, nonlinear_message=False,
+                 alpha_drop=0.1, proj_drop=0.1, drop_path_rate=0.0, irreps_mlp_mid=None, norm_layer="layer"):
+        super().__init__()
+        assert norm_layer == "layer" and drop_path_rate == 0.0
+        irreps_node_input, irreps_node_output = Irreps(irreps_node_input), Irreps(irreps_node_output)
+        self.norm_1 = EquivariantLayerNormV2(irreps_node_input)
+        self.ga = GraphAttention(irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_input, fc_neurons,
+                                 irreps_head, num_heads, irreps_pre_attn, rescale_degree, nonlinear_message,
+                                 alpha_drop, proj_drop)
+        self.norm_2 = EquivariantLayerNormV2(irreps_node_input)
+        self.ffn = FeedForwardNetwork(irreps_node_input, irreps_node_attr, irreps_node_output, irreps_mlp_mid, proj_drop)
+        self.ffn_shortcut = None
+        if irreps_node_input != irreps_node_output:
+            self.ffn_shortcut = FullyConnectedTensorProductRescale(irreps_node_input, irreps_node_attr,
+                                                                   irreps_node_output, bias=True, rescale=_RESCALE)
+
+    def forward(self, x, node_attr, edge_src, edge_dst, edge_attr, edge_scalars):
+        out = x + self.ga(self.norm_1(x), edge_src, edge_dst, edge_attr, edge_scalars)
+        f = self.ffn(self.norm_2(out), node_attr)
+        if self.ffn_shortcut is not None:
+            out = self.ffn_shortcut(out, node_attr)
+        return out + f
+
+
+class NodeEmbeddingNetwork(nn.Module):
+    def __init__(self, irreps_node_embedding, max_atom_type, bias=True):
+        super().__init__()
+        self.max_atom_type = max_atom_type
+        self.atom_type_lin = LinearRS(Irreps("{}x0e".format(max_atom_type)), Irreps(irreps_node_embedding), bias=bias)
+        self.atom_type_lin.tp.weight.data.mul_(max_atom_type ** 0.5)
+
+    def forward(self, node_atom):
+        onehot = torch.nn.functional.one_hot(node_atom, self.max_atom_type).to(self.atom_type_lin.tp.weight.dtype)
+        return self.atom_type_lin(onehot), onehot, onehot
+
+
+class ScaledScatter(nn.Module):
+    def __init__(self, avg):
+        super().__init__()
+        self.avg_aggregate_num = avg + 0.0
+
+    def forward(self, x, index, dim_size):
+        return scatter_sum(x, index, dim_size) / (self.avg_aggregate_num ** 0.5)
+
+
+class EdgeDegreeEmbeddingNetwork(nn.Module):
+    def __init__(self, irreps_node_embedding, irreps_edge_attr, fc_neurons, avg_aggregate_num):
+        super().__init__()
+        self.exp = LinearRS(Irreps("1x0e"), irreps_node_embedding, bias=_USE_BIAS, rescale=_RESCALE)
+        self.dw = DepthwiseTensorProduct(irreps_node_embedding, irreps_edge_attr, irreps_node_embedding,
+                                         internal_weights=False, bias=False)
+        self.rad = RadialProfile(fc_neurons + [self.dw.tp.weight_numel])
+        for sl, k in self.dw.slices_sqrt_k.values():
+            self.rad.net[-1].weight.data[sl, :] *= k
+            self.rad.offset.data[sl] *= k
+        self.proj = LinearRS(self.dw.irreps_out.simplify(), irreps_node_embedding)
+        self.scale_scatter = ScaledScatter(avg_aggregate_num)
+
+    def forward(self, node_input, edge_attr, edge_scalars, edge_src, edge_dst):
+        f = self.exp(torch.ones_like(node_input[:, 0:1]))
+        e = self.proj(self.dw(f[edge_src], edge_attr, self.rad(edge_scalars)))
+        return self.scale_scatter(e, edge_dst, f.shape[0])
+
+
+class _Base(nn.Module):
+    """Shared trunk of the three model variants."""
+
+    def _build(self, irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius, number_of_basis,
+               basis_type, fc_neurons, irreps_feature, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
+               nonlinear_message, irreps_mlp_mid, alpha_drop, max_atom_type, avg_degree, avg_nodes):
+        self.max_radius, self.number_of_basis = max_radius, number_of_basis
+        self.irreps_node_embedding = Irreps(irreps_node_embedding)
+        self.irreps_feature = Irreps(irreps_feature)
+        self.irreps_edge_attr = Irreps(irreps_sh)
+        self.lmax_sh = self.irreps_edge_attr.lmax
+        self.fc_neurons = [number_of_basis] + fc_neurons
+        self.atom_embed = NodeEmbeddingNetwork(self.irreps_node_embedding, max_atom_type)
+        if basis_type == "gaussian":
+            self.rbf = GaussianRadialBasisLayer(number_of_basis, cutoff=max_radius)
+        elif basis_type == "exp":
+            self.rbf = ExpNormalSmearing(0.0, max_radius, number_of_basis)
+        else:
+            raise ValueError
+        self.edge_deg_embed = EdgeDegreeEmbeddingNetwork(self.irreps_node_embedding, self.irreps_edge_attr,
+                                                         self.fc_neurons, avg_degree)
+        self.blocks = nn.ModuleList()
+        for i in range(num_layers):
+            out = self.irreps_node_embedding if i != num_layers - 1 else self.irreps_feature
+            self.blocks.append(TransBlock(self.irreps_node_embedding, irreps_node_attr, self.irreps_edge_attr, out,
+                                          self.fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
+                                          nonlinear_message, alpha_drop, 0.0, 0.0, irreps_mlp_mid, "layer"))
+        self.norm = EquivariantLayerNormV2(self.irreps_feature)
+        self.head = nn.Sequential(LinearRS(self.irreps_feature, self.irreps_feature, rescale=_RESCALE),
+                                  Activation(self.irreps_feature, [torch.nn.functional.silu]),
+                                  LinearRS(self.irreps_feature, Irreps("1x0e"), rescale=_RESCALE))
+        self.scale_scatter = ScaledScatter(avg_nodes)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _trunk(self, node_embedding, pos, batch, edge_src, edge_dst, edge_vec, num_graphs):
+        edge_sh = spherical_harmonics(self.lmax_sh, edge_vec, normalize=True, normalization="component")
+        edge_len = edge_vec.norm(dim=1)
+        edge_emb = self.rbf(edge_len)
+        x = node_embedding + self.edge_deg_embed(node_embedding, edge_sh, edge_emb, edge_src, edge_dst)
+        node_attr = torch.ones_like(x[:, 0:1])
+        for blk in self.blocks:
+            x = blk(x, node_attr, edge_src, edge_dst, edge_sh, edge_emb)
+        x = self.head(self.norm(x))
+        return self.scale_scatter(x, batch, num_graphs)
+
+
+_QM9_AVG_NUM_NODES = 18.03065905448718
+_QM9_AVG_DEGREE = 15.57930850982666
+
+
+class GraphAttentionTransformer(_Base):
+    def __init__(self, irreps_in="5x0e", irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6,
+                 irreps_node_attr="1x0e", irreps_sh="1x0e+1x1e+1x2e", max_radius=5.0, number_of_basis=128,
+                 basis_type="gaussian", fc_neurons=[64, 64], irreps_feature="512x0e",
+                 irreps_head="32x0e+16x1o+8x2e", num_heads=4, irreps_pre_attn=None, rescale_degree=False,
+                 nonlinear_message=False, irreps_mlp_mid="128x0e+64x1e+32x2e", norm_layer="layer", alpha_drop=0.2,
+                 proj_drop=0.0, out_drop=0.0, drop_path_rate=0.0, mean=None, std=None, scale=None, atomref=None):
+        super().__init__()
+        self.task_mean, self.task_std, self.scale = mean, std, scale
+        self.register_buffer("atomref", atomref)
+        self._build(irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius, number_of_basis,
+                    basis_type, list(fc_neurons), irreps_feature, irreps_head, num_heads, irreps_pre_attn,
+                    rescale_degree, nonlinear_message, irreps_mlp_mid, alpha_drop, 5, _QM9_AVG_DEGREE,
+                    _QM9_AVG_NUM_NODES)
+
+    def forward(self, f_in, pos, batch, node_atom, **kwargs):
+        edge_src, edge_dst = radius_graph(pos, self.max_radius, batch, 1000)
+        edge_vec = pos[edge_src] - pos[edge_dst]
+        node_atom = node_atom.new_tensor([-1, 0, -1, -1, -1, -1, 1, 2, 3, 4])[node_atom]
+        emb, _, _ = self.atom_embed(node_atom)
+        out = self._trunk(emb, pos, batch, edge_src, edge_dst, edge_vec, int(batch.max()) + 1)
+        return out if self.scale is None else self.scale * out
+
+
+class GraphAttentionTransformerMD17(_Base):
+    def __init__(self, irreps_in="64x0e", irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6,
+                 irreps_node_attr="1x0e", irreps_sh="1x0e+1x1e+1x2e", max_radius=5.0, number_of_basis=128,
+                 basis_type="gaussian", fc_neurons=[64, 64], irreps_feature="512x0e",
+                 irreps_head="32x0e+16x1o+8x2e", num_heads=4, irreps_pre_attn=None, rescale_degree=False,
+                 nonlinear_message=False, irreps_mlp_mid="128x0e+64x1e+32x2e", use_attn_head=False,
+                 norm_layer="layer", alpha_drop=0.2, proj_drop=0.0, out_drop=0.0, drop_path_rate=0.0, mean=None,
+                 std=None, scale=None, atomref=None):
+        super().__init__()
+        assert not use_attn_head
+        self.task_mean, self.task_std, self.scale = mean, std, scale
+        self.register_buffer("atomref", atomref)
+        self._build(irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius, number_of_basis,
+                    basis_type, list(fc_neurons), irreps_feature, irreps_head, num_heads, irreps_pre_attn,
+                    rescale_degree, nonlinear_message, irreps_mlp_mid, alpha_drop, 64, _QM9_AVG_DEGREE,
+                    _QM9_AVG_NUM_NODES)
+
+    @torch.enable_grad()
+    def forward(self, node_atom, pos, batch):
+        pos = pos.requires_grad_(True)
+        edge_src, edge_dst = radius_graph(pos, self.max_radius, batch, 1000)
+        edge_vec = pos[edge_src] - pos[edge_dst]
+        emb, _, _ = self.atom_embed(node_atom)
+        energy = self._trunk(emb, pos, batch, edge_src, edge_dst, edge_vec, int(batch.max()) + 1)
+        if self.scale is not None:
+            energy = self.scale * energy
+        forces = -1 * torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), create_graph=True)[0]
+        return energy, forces
+
+
+class GraphAttentionTransformerOC20(_Base):
+    """Energy path only; edges (edge_index + per-edge Cartesian offsets) are supplied by the caller, which is what
+    ocpmodels' radius_graph_pbc/get_pbc_distances produce upstream (graph_attention_transformer_oc20.py:267-302)."""
+
+    def __init__(self, num_atoms=None, bond_feat_dim=None, num_targets=1, irreps_node_embedding="256x0e+128x1e",
+                 num_layers=6, irreps_node_attr="1x0e", use_node_attr=False, irreps_sh="1x0e+1x1e", max_radius=6.0,
+                 number_of_basis=128, fc_neurons=[64, 64], irreps_feature="512x0e", irreps_head="32x0e+16x1e",
+                 num_heads=8, irreps_pre_attn=None, rescale_degree=False, nonlinear_message=False,
+                 irreps_mlp_mid="768x0e+384x1e", norm_layer="layer", alpha_drop=0.2, proj_drop=0.0, out_drop=0.0,
+                 drop_path_rate=0.0, max_neighbors=50, **unused):
+        super().__init__()
+        assert not use_node_attr
+        self.max_neighbors = max_neighbors
+        self._build(irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius, number_of_basis,
+                    "gaussian", list(fc_neurons), irreps_feature, irreps_head, num_heads, irreps_pre_attn,
+                    rescale_degree, nonlinear_message, irreps_mlp_mid, alpha_drop, 84, 23.395238876342773, 77.81317)
+        self.tag_embed = NodeEmbeddingNetwork(self.irreps_node_embedding, 3)
+
+    def forward(self, atomic_numbers, tags, pos, batch, edge_index=None, offsets=None):
+        if edge_index is None:
+            edge_src, edge_dst = radius_graph(pos, self.max_radius, batch, self.max_neighbors)
+        else:
+            edge_src, edge_dst = edge_index[0], edge_index[1]
+        edge_vec = pos[edge_src] - pos[edge_dst]
+        if offsets is not None:
+            edge_vec = edge_vec + offsets
+        emb, _, _ = self.atom_embed(atomic_numbers.long())
+        tag, _, _ = self.tag_embed(tags.long())
+        return self._trunk(emb + tag, pos, batch, edge_src, edge_dst, edge_vec, int(batch.max()) + 1)
+
+
+# ---------------------------------------------------------------------------- factories (registered names)
+def graph_attention_transformer_l2(irreps_in, radius, num_basis=128, atomref=None, task_mean=None, task_std=None,
+                                   **kwargs):
+    return GraphAttentionTransformer(
+        irreps_in=irreps_in, irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6, irreps_node_attr="1x0e",
+        irreps_sh="1x0e+1x1e+1x2e", max_radius=radius, number_of_basis=num_basis, fc_neurons=[64, 64],
+        irreps_feature="512x0e", irreps_head="32x0e+16x1e+8x2e", num_heads=4, rescale_degree=False,
+        nonlinear_message=False, irreps_mlp_mid="384x0e+192x1e+96x2e", alpha_drop=0.2, mean=task_mean, std=task_std,
+        atomref=atomref)
+
+
+def graph_attention_transformer_nonlinear_l2(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                             task_std=None, **kwargs):
+    return GraphAttentionTransformer(
+        irreps_in=irreps_in, irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6, irreps_node_attr="1x0e",
+        irreps_sh="1x0e+1x1e+1x2e", max_radius=radius, number_of_basis=num_basis, fc_neurons=[64, 64],
+        irreps_feature="512x0e", irreps_head="32x0e+16x1e+8x2e", num_heads=4, rescale_degree=False,
+        nonlinear_message=True, irreps_mlp_mid="384x0e+192x1e+96x2e", alpha_drop=0.2, mean=task_mean, std=task_std,
+        atomref=atomref)
+
+
+def graph_attention_transformer_nonlinear_exp_l2_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                      task_std=None, **kwargs):
+    return GraphAttentionTransformerMD17(
+        irreps_in=irreps_in, irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6, irreps_node_attr="1x0e",
+        irreps_sh="1x0e+1x1e+1x2e", max_radius=radius, number_of_basis=num_basis, fc_neurons=[64, 64],
+        basis_type="exp", irreps_feature="512x0e", irreps_head="32x0e+16x1e+8x2e", num_heads=4,
+        rescale_degree=False, nonlinear_message=True, irreps_mlp_mid="384x0e+192x1e+96x2e", alpha_drop=0.0,
+        mean=task_mean, std=task_std, atomref=atomref)
+
+
+def graph_attention_transformer_nonlinear_exp_l3_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                      task_std=None, **kwargs):
+    return GraphAttentionTransformerMD17(
+        irreps_in=irreps_in, irreps_node_embedding="128x0e+64x1e+64x2e+32x3e", num_layers=6, irreps_node_attr="1x0e",
+        irreps_sh="1x0e+1x1e+1x2e+1x3e", max_radius=radius, number_of_basis=num_basis, fc_neurons=[64, 64],
+        basis_type="exp", irreps_feature="512x0e", irreps_head="32x0e+16x1e+16x2e+8x3e", num_heads=4,
+        rescale_degree=False, nonlinear_message=True, irreps_mlp_mid="384x0e+192x1e+192x2e+96x3e", alpha_drop=0.0,
+        mean=task_mean, std=task_std, atomref=atomref)
+
+
+def oc20_l1_256_nonlinear(**kwargs):
+    """oc20/configs/is2re/all/graph_attention_transformer/l1_256_nonlinear_g@2_local.yml model section."""
+    cfg = dict(irreps_node_embedding="256x0e+128x1e", num_layers=6, irreps_sh="1x0e+1x1e", max_radius=5.0,
+               number_of_basis=128, fc_neurons=[64, 64], irreps_feature="512x0e", irreps_head="32x0e+16x1e",
+               num_heads=8, nonlinear_message=True, irreps_mlp_mid="768x0e+384x1e", alpha_drop=0.2,
+               max_neighbors=500)
+    cfg.update(kwargs)
+    return GraphAttentionTransformerOC20(**cfg)
+
+
+ENTRYPOINTS = {
+    "graph_attention_transformer_l2": graph_attention_transformer_l2,
+    "graph_attention_transformer_nonlinear_l2": graph_attention_transformer_nonlinear_l2,
+    "graph_attention_transformer_nonlinear_exp_l2_md17": graph_attention_transformer_nonlinear_exp_l2_md17,
+    "graph_attention_transformer_nonlinear_exp_l3_md17": graph_attention_transformer_nonlinear_exp_l3_md17,
+}
+
+
+def model_entrypoint(name):
+    return ENTRYPOINTS[name]
