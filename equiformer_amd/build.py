@@ -1,0 +1,52 @@
+"""Build libequiformer_hip.so (all HIP kernels + the C ABI of include/equiformer_hip.h) for gfx950.
+
+    python -m equiformer_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The library is built IN-TREE (equiformer_amd/libequiformer_hip.so) so that it
+travels with the repository snapshot to the GPU box; it links against libamdhip64 only (no torch).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libequiformer_hip.so")
+SOURCES = ["gemm.hip", "rowops.hip", "edge.hip", "graph.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "equiformer_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,520 @@
+// Dense contractions of the Equiformer hot path on the gfx950 matrix cores.
+//
+// Everything here is exact fp32 (v_mfma_f32_32x32x2_f32: 157 TFLOP/s peak on MI355X, bit-equal to an fmaf
+// chain), because the parity bar against the reference is 1e-4 relative in fp32.
+//
+// One kernel family, two shapes:
+//   rows kernel : C[i,n] = sum_k A[i,k] B[k,n]     i = feature rows (nodes / edges x (2l+1)), large
+//                 A operand either read from memory (two-level rows, k contiguous) or GENERATED on the fly by
+//                 the depth-wise tensor product (x, coupling, w) -> the 3136-wide DTP output never exists in HBM.
+//                 B operand either [K,N] (forward) or [N,K] (data gradient).
+//   tn kernel   : C[m,n] += sum_i A[i,m] B[i,n]    weight gradients; reduction over the rows, split over the
+//                 grid and over the 4 waves of a block, fp32 atomics into C.
+// LDS tiles are stored k-major (T[k][x]) so that the MFMA operand fetch (lane = x, one k per half-wave) is a
+// conflict-free ds_read_b32; sources that are contiguous along k are transposed while staging (odd row stride),
+// sources contiguous along x are staged with ds_write_b128 (stride = 4 mod 8 floats).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+constexpr int MAX_SLABS = 32;  // K (channels of one DTP output degree) <= 1024
+
+struct Rows {
+  const float* base;
+  int d, ld, inner;
+};
+
+struct DtpSlab {  // one 32-channel slab of the generated A operand
+  int d1;         // 2*l1+1
+  int x_off;      // offset of (segment l1, channel u0) in the x row
+  int x_mul;      // multiplicity of that segment (stride between components i)
+  int w_off;      // offset of the slab's weights in the w row
+  int m_off;      // offset of the path's coupling matrix in the coupling row
+};
+
+struct DtpA {
+  const float* x;
+  const float* coupling;
+  const float* w;  // may be null
+  int x_ld, m_ld, w_ld;
+  int d3;   // 2*l3+1
+  int ept;  // edges per tile (rows kernel: per M tile; tn kernel: per reduction step)
+  DtpSlab slabs[MAX_SLABS];
+};
+
+// ------------------------------------------------------------------------------------------------
+// LDS staging
+// ------------------------------------------------------------------------------------------------
+// source rows run over the tile's x index and are contiguous along k  ->  T[k][x], SX odd
+template <int BX, int SX>
+__device__ __forceinline__ void fill_contigk(float* __restrict__ T, const Rows& R, int x0, int xcnt, int k0, int K,
+                                             bool vec) {
+  const int t = threadIdx.x;
+  const int kq = t & 7, xr0 = t >> 3;
+#pragma unroll
+  for (int pass = 0; pass < BX / 32; ++pass) {
+    const int xr = xr0 + pass * 32;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int krem = K - (k0 + kq * 4);
+    if (xr < xcnt && krem > 0) {
+      const float* p = R.base + row_off2(x0 + xr, R.d, R.ld, R.inner) + k0 + kq * 4;
+      if (vec && krem >= 4) {
+        v = *reinterpret_cast<const float4*>(p);
+      } else {
+        v.x = p[0];
+        if (krem > 1) v.y = p[1];
+        if (krem > 2) v.z = p[2];
+        if (krem > 3) v.w = p[3];
+      }
+    }
+    float* q = T + (kq * 4) * SX + xr;
+    q[0] = v.x;
+    q[SX] = v.y;
+    q[2 * SX] = v.z;
+    q[3 * SX] = v.w;
+  }
+}
+
+// source rows run over the reduction index k (two-level) and are contiguous along x  ->  T[k][x], SX % 4 == 0
+template <int BX, int SX>
+__device__ __forceinline__ void fill_natural(float* __restrict__ T, const Rows& R, int k0, int kcnt, int x0, int X,
+                                             bool vec) {
+  constexpr int XQ = BX / 4;
+  constexpr int RPP = NTHREADS / XQ;
+  const int t = threadIdx.x;
+  const int xq = t % XQ, kr0 = t / XQ;
+#pragma unroll
+  for (int pass = 0; pass < BK / RPP; ++pass) {
+    const int kr = kr0 + pass * RPP;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int x = x0 + xq * 4;
+    const int xrem = X - x;
+    if (kr < kcnt && xrem > 0) {
+      const float* p = R.base + row_off2(k0 + kr, R.d, R.ld, R.inner) + x;
+      if (vec && xrem >= 4) {
+        v = *reinterpret_cast<const float4*>(p);
+      } else {
+        v.x = p[0];
+        if (xrem > 1) v.y = p[1];
+        if (xrem > 2) v.z = p[2];
+        if (xrem > 3) v.w = p[3];
+      }
+    }
+    *reinterpret_cast<float4*>(T + kr * SX + xq * 4) = v;
+  }
+}
+
+// value of the DTP output for (edge e, slab channel u), all d3 components, written through `put(m3, value)`
+template <typename Put>
+__device__ __forceinline__ void dtp_generate(const DtpA& D, const DtpSlab& s, long e, int u, Put put) {
+  const float wv = D.w ? D.w[e * D.w_ld + s.w_off + u] : 1.0f;
+  const float* xp = D.x + e * D.x_ld + s.x_off + u;
+  const float* mp = D.coupling + e * D.m_ld + s.m_off;
+  float xv[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) xv[i] = (i < s.d1) ? xp[i * s.x_mul] : 0.f;
+  for (int m3 = 0; m3 < D.d3; ++m3) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (i < s.d1) acc = fmaf(mp[i * D.d3 + m3], xv[i], acc);
+    put(m3, acc * wv);
+  }
+}
+
+// rows kernel: A tile rows are (edge_local, m3), k = slab channel -> As[u][el*d3+m3]
+template <int SA>
+__device__ __forceinline__ void fill_dtp_rows(float* __restrict__ As, const DtpA& D, int e0, int ecnt, int slab) {
+  const int u = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const DtpSlab s = D.slabs[slab];
+  for (int el = g; el < ecnt; el += 8) {
+    float* q = As + u * SA + el * D.d3;
+    dtp_generate(D, s, (long)(e0 + el), u, [&](int m3, float v) { q[m3] = v; });
+  }
+}
+
+// tn kernel: reduction rows are (edge_local, m3), the M index is the DTP channel -> As[el*d3+m3][sl*32+u]
+template <int BM, int SA>
+__device__ __forceinline__ void fill_dtp_tn(float* __restrict__ As, const DtpA& D, int e0, int ecnt, int slab0,
+                                            int nslab) {
+  const int u = threadIdx.x & 31, g = threadIdx.x >> 5;
+  constexpr int SL = BM / 32;
+  // zero first (rows of invalid edges / padding rows must not inject NaNs into the reduction)
+  for (int i = threadIdx.x; i < BK * SA; i += NTHREADS) As[i] = 0.f;
+  __syncthreads();
+  for (int item = g; item < ecnt * SL; item += 8) {
+    const int el = item / SL, sl = item - el * SL;
+    if (sl >= nslab) continue;
+    const DtpSlab s = D.slabs[slab0 + sl];
+    float* q = As + (el * D.d3) * SA + sl * 32 + u;
+    dtp_generate(D, s, (long)(e0 + el), u, [&](int m3, float v) { q[m3 * SA] = v; });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA over one staged K step
+// ------------------------------------------------------------------------------------------------
+template <int TM, int TN, int SA, int SB>
+__device__ __forceinline__ void mma_step(const float* __restrict__ As, const float* __restrict__ Bs, int wm0, int wn0,
+                                         int kbeg, int kend, f32x16 (&acc)[TM][TN]) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, hi = lane >> 5;
+#pragma unroll 4
+  for (int kk = kbeg; kk < kend; kk += 2) {
+    float a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = As[(kk + hi) * SA + wm0 + i * 32 + r];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + hi) * SB + wn0 + j * 32 + r];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows kernel
+// ------------------------------------------------------------------------------------------------
+struct RowsArgs {
+  Rows A, B, C;
+  const float* bias;
+  int M, N, K;
+  int rows_per_tile;
+  int accumulate;
+  int vecA, vecB;
+  DtpA dtp;
+};
+
+enum { A_MEM = 0, A_DTP = 1 };
+enum { B_KN = 0, B_NK = 1 };
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+  constexpr int SA = BM + 1;
+  constexpr int SB = (BMODE == B_KN) ? BN + 4 : BN + 1;
+  __shared__ __attribute__((aligned(16))) float As[BK * SA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
+
+  const int m0 = blockIdx.x * g.rows_per_tile;
+  const int n0 = blockIdx.y * BN;
+  const int mcnt = min(g.rows_per_tile, g.M - m0);
+  const int wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  int e0 = 0, ecnt = 0;
+  if (AMODE == A_DTP) {
+    e0 = blockIdx.x * g.dtp.ept;
+    ecnt = mcnt / g.dtp.d3;
+  }
+
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    if (AMODE == A_MEM)
+      fill_contigk<BM, SA>(As, g.A, m0, mcnt, k0, g.K, g.vecA);
+    else
+      fill_dtp_rows<SA>(As, g.dtp, e0, ecnt, k0 / BK);
+    if (BMODE == B_KN)
+      fill_natural<BN, SB>(Bs, g.B, k0, min(BK, g.K - k0), n0, g.N, g.vecB);
+    else
+      fill_contigk<BN, SB>(Bs, g.B, n0, min(BN, g.N - n0), k0, g.K, g.vecB);
+    __syncthreads();
+    mma_step<TM, TN, SA, SB>(As, Bs, wm0, wn0, 0, BK, acc);
+    __syncthreads();
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + j * 32 + r;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;
+        if (row < mcnt) {
+          float* p = const_cast<float*>(g.C.base) + row_off2(m0 + row, g.C.d, g.C.ld, g.C.inner) + col;
+          float v = acc[i][j][q] + bv;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tn kernel (weight gradients): C[m,n] += sum_rows A[row,m] B[row,n]
+// ------------------------------------------------------------------------------------------------
+struct TnArgs {
+  Rows A, B;
+  float* C;
+  int ldc;
+  int M, N, R;
+  int rows_per_step;    // reduction rows staged per K step (<= BK)
+  int steps_per_split;  // K steps handled by one blockIdx.z
+  int vecA, vecB;
+  DtpA dtp;
+};
+
+template <int BM, int BN, int WM, int WN, int WK, int AMODE>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(WM * WN * WK == 4 && TM >= 1 && TN >= 1, "4 waves");
+  constexpr int SA = BM + 4, SB = BN + 4;
+  __shared__ __attribute__((aligned(16))) float As[BK * SA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wave = threadIdx.x >> 6;
+  const int wk = wave % WK;
+  const int wmn = wave / WK;
+  const int wm0 = (wmn / WN) * (TM * 32), wn0 = (wmn % WN) * (TN * 32);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const int total_steps = (g.R + g.rows_per_step - 1) / g.rows_per_step;
+  const int s_beg = blockIdx.z * g.steps_per_split;
+  const int s_end = min(total_steps, s_beg + g.steps_per_split);
+  const int nslab = min(BM, g.M - m0) / 32;
+
+  for (int s = s_beg; s < s_end; ++s) {
+    const int r0 = s * g.rows_per_step;
+    const int rcnt = min(g.rows_per_step, g.R - r0);
+    if (AMODE == A_MEM)
+      fill_natural<BM, SA>(As, g.A, r0, rcnt, m0, g.M, g.vecA);
+    else
+      fill_dtp_tn<BM, SA>(As, g.dtp, s * g.dtp.ept, rcnt / g.dtp.d3, m0 / 32, nslab);
+    fill_natural<BN, SB>(Bs, g.B, r0, rcnt, n0, g.N, g.vecB);
+    __syncthreads();
+    mma_step<TM, TN, SA, SB>(As, Bs, wm0, wn0, wk * (BK / WK), (wk + 1) * (BK / WK), acc);
+    __syncthreads();
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + j * 32 + r;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = m0 + wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;
+        if (row < g.M) atomicAdd(g.C + (long)row * g.ldc + col, acc[i][j][q]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool rows_vec_ok(const float* base, const eqf_rows& r) {
+  return aligned16(base) && (r.ld % 4 == 0) && (r.inner % 4 == 0);
+}
+
+template <int AMODE, int BMODE>
+int launch_rows(RowsArgs& a, hipStream_t st) {
+  const int mt = eqf_cdiv(a.M, a.rows_per_tile);
+  if (a.M <= 0 || a.N <= 0) return 0;
+  if (a.N > 64) {
+    dim3 grid(mt, eqf_cdiv(a.N, 128));
+    hipLaunchKernelGGL((gemm_rows_kernel<128, 128, 2, 2, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
+  } else if (a.N > 32) {
+    dim3 grid(mt, 1);
+    hipLaunchKernelGGL((gemm_rows_kernel<128, 64, 2, 2, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
+  } else {
+    dim3 grid(mt, 1);
+    hipLaunchKernelGGL((gemm_rows_kernel<128, 32, 4, 1, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
+  }
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int AMODE>
+int launch_tn(TnArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0 || a.R <= 0) return 0;
+  const bool bm64 = !(a.M % 64 != 0 && a.M < 256);
+  const bool bn64 = !(a.N % 64 != 0 && a.N < 256);
+  const int BMv = bm64 ? 64 : 32, BNv = bn64 ? 64 : 32;
+  const int tiles = eqf_cdiv(a.M, BMv) * eqf_cdiv(a.N, BNv);
+  const int total_steps = eqf_cdiv(a.R, a.rows_per_step);
+  int ksplit = 2048 / tiles;
+  if (ksplit < 1) ksplit = 1;
+  int max_split = eqf_cdiv(total_steps, 8);  // at least 8 K steps per block
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  a.steps_per_split = eqf_cdiv(total_steps, ksplit);
+  ksplit = eqf_cdiv(total_steps, a.steps_per_split);
+  dim3 grid(eqf_cdiv(a.M, BMv), eqf_cdiv(a.N, BNv), ksplit);
+  if (bm64 && bn64)
+    hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 2, 2, 1, AMODE>), grid, dim3(NTHREADS), 0, st, a);
+  else if (bm64)
+    hipLaunchKernelGGL((gemm_tn_kernel<64, 32, 2, 1, 2, AMODE>), grid, dim3(NTHREADS), 0, st, a);
+  else if (bn64)
+    hipLaunchKernelGGL((gemm_tn_kernel<32, 64, 1, 2, 2, AMODE>), grid, dim3(NTHREADS), 0, st, a);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<32, 32, 1, 1, 4, AMODE>), grid, dim3(NTHREADS), 0, st, a);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Build the per-slab table of output degree l3; returns K (channels of that degree) or <0 on error.
+int build_dtp(const eqf_dtp_paths* P, int l3, const float* x, const float* coupling, const float* w, DtpA& D,
+              int* out_off) {
+  D.x = x;
+  D.coupling = coupling;
+  D.w = w;
+  D.x_ld = P->in_dim;
+  D.m_ld = P->m_numel;
+  D.w_ld = P->w_numel;
+  D.d3 = 2 * l3 + 1;
+  int K = 0;
+  *out_off = -1;
+  for (int p = 0; p < P->npaths; ++p)
+    if (P->l3[p] == l3) {
+      K = P->out_k[p];
+      *out_off = P->out_off[p];
+    }
+  if (K == 0) return 0;
+  if (K % 32 != 0 || K / 32 > MAX_SLABS) return EQF_E_UNSUPPORTED;
+  for (int s = 0; s < K / 32; ++s) D.slabs[s].d1 = 0;
+  for (int p = 0; p < P->npaths; ++p) {
+    if (P->l3[p] != l3) continue;
+    if (P->mul[p] % 32 != 0 || P->out_ch[p] % 32 != 0) return EQF_E_UNSUPPORTED;
+    if (P->l1[p] > 3) return EQF_E_UNSUPPORTED;
+    for (int c = 0; c < P->mul[p]; c += 32) {
+      DtpSlab& s = D.slabs[(P->out_ch[p] + c) / 32];
+      s.d1 = 2 * P->l1[p] + 1;
+      s.x_off = P->in_off[p] + c;
+      s.x_mul = P->mul[p];
+      s.w_off = P->w_off[p] + c;
+      s.m_off = P->m_off[p];
+    }
+  }
+  for (int s = 0; s < K / 32; ++s)
+    if (D.slabs[s].d1 == 0) return EQF_E_BADARG;
+  return K;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eqf_gemm_nn(const float* A, eqf_rows ra, const float* B, int ldb, float* C, eqf_rows rc, const float* bias, int M,
+                int N, int K, int accumulate, void* stream) {
+  if (!A || !B || !C || ra.d < 1 || rc.d < 1) return EQF_E_BADARG;
+  RowsArgs a{};
+  a.A = {A, ra.d, ra.ld, ra.inner};
+  a.B = {B, 1, ldb, 0};
+  a.C = {C, rc.d, rc.ld, rc.inner};
+  a.bias = bias;
+  a.M = M, a.N = N, a.K = K, a.rows_per_tile = 128, a.accumulate = accumulate;
+  a.vecA = rows_vec_ok(A, ra);
+  a.vecB = aligned16(B) && ldb % 4 == 0;
+  return launch_rows<A_MEM, B_KN>(a, (hipStream_t)stream);
+}
+
+int eqf_gemm_nt(const float* A, eqf_rows ra, const float* B, int ldb, float* C, eqf_rows rc, const float* bias, int M,
+                int N, int K, int accumulate, void* stream) {
+  if (!A || !B || !C || ra.d < 1 || rc.d < 1) return EQF_E_BADARG;
+  RowsArgs a{};
+  a.A = {A, ra.d, ra.ld, ra.inner};
+  a.B = {B, 1, ldb, 0};
+  a.C = {C, rc.d, rc.ld, rc.inner};
+  a.bias = bias;
+  a.M = M, a.N = N, a.K = K, a.rows_per_tile = 128, a.accumulate = accumulate;
+  a.vecA = rows_vec_ok(A, ra);
+  a.vecB = aligned16(B) && ldb % 4 == 0;
+  return launch_rows<A_MEM, B_NK>(a, (hipStream_t)stream);
+}
+
+int eqf_gemm_tn(const float* A, eqf_rows ra, const float* B, eqf_rows rb, float* C, int ldc, int M, int N, int R,
+                void* stream) {
+  if (!A || !B || !C || ra.d < 1 || rb.d < 1) return EQF_E_BADARG;
+  TnArgs a{};
+  a.A = {A, ra.d, ra.ld, ra.inner};
+  a.B = {B, rb.d, rb.ld, rb.inner};
+  a.C = C, a.ldc = ldc, a.M = M, a.N = N, a.R = R;
+  a.rows_per_step = BK;
+  a.vecA = rows_vec_ok(A, ra);
+  a.vecB = rows_vec_ok(B, rb);
+  return launch_tn<A_MEM>(a, (hipStream_t)stream);
+}
+
+int eqf_dtp_linear_fwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                       const float* const* Wl, const float* bias0, float* out, const eqf_irreps* out_irreps, int E,
+                       void* stream) {
+  if (!x || !coupling || !paths || !Wl || !out || !out_irreps) return EQF_E_BADARG;
+  const int Dout = irreps_dim(*out_irreps);
+  int off = 0;
+  for (int s = 0; s < out_irreps->nseg; ++s) {
+    const int l3 = out_irreps->l[s], N = out_irreps->mul[s], d3 = 2 * l3 + 1;
+    RowsArgs a{};
+    int dtp_off;
+    const int K = build_dtp(paths, l3, x, coupling, w, a.dtp, &dtp_off);
+    if (K < 0) return K;
+    if (K == 0) return EQF_E_BADARG;  // an output degree nothing feeds
+    a.dtp.ept = 128 / d3;
+    a.B = {Wl[l3], 1, N, 0};
+    a.C = {out + off, d3, Dout, N};
+    a.bias = (l3 == 0) ? bias0 : nullptr;
+    a.M = E * d3, a.N = N, a.K = K, a.rows_per_tile = a.dtp.ept * d3, a.accumulate = 0;
+    a.vecA = 0;
+    a.vecB = aligned16(Wl[l3]) && N % 4 == 0;
+    int rc = launch_rows<A_DTP, B_KN>(a, (hipStream_t)stream);
+    if (rc) return rc;
+    off += N * d3;
+  }
+  return 0;
+}
+
+int eqf_dtp_linear_wgrad(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                         const float* d_out, const eqf_irreps* out_irreps, float* const* dWl, int E, void* stream) {
+  if (!x || !coupling || !paths || !d_out || !dWl || !out_irreps) return EQF_E_BADARG;
+  const int Dout = irreps_dim(*out_irreps);
+  int off = 0;
+  for (int s = 0; s < out_irreps->nseg; ++s) {
+    const int l3 = out_irreps->l[s], N = out_irreps->mul[s], d3 = 2 * l3 + 1;
+    TnArgs a{};
+    int dtp_off;
+    const int K = build_dtp(paths, l3, x, coupling, w, a.dtp, &dtp_off);
+    if (K < 0) return K;
+    if (K == 0) return EQF_E_BADARG;
+    a.dtp.ept = BK / d3;
+    a.B = {d_out + off, d3, Dout, N};
+    a.C = dWl[l3], a.ldc = N, a.M = K, a.N = N, a.R = E * d3;
+    a.rows_per_step = a.dtp.ept * d3;
+    a.vecA = 0;
+    a.vecB = aligned16(d_out + off) && Dout % 4 == 0 && N % 4 == 0;
+    int rc = launch_tn<A_DTP>(a, (hipStream_t)stream);
+    if (rc) return rc;
+    off += N * d3;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,387 @@
+// Graph construction and edge geometry: radius graph -> dst-sorted CSR, edge vectors, spherical harmonics,
+// radial basis.  Molecules are tiny (N ~ 18-80 atoms), so one workgroup owns one molecule and brute-forces its
+// pairs out of L1; the output is already sorted by destination (the order the segmented kernels want).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(64) void radius_count_kernel(const float* __restrict__ pos, const int* __restrict__ mol_ptr,
+                                                          float r2, int max_nbr, int* __restrict__ deg) {
+  const int b = blockIdx.x;
+  const int n0 = mol_ptr[b], n1 = mol_ptr[b + 1];
+  for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
+    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    int c = 0;
+    for (int j = n0; j < n1; ++j) {
+      const float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      if (j != i && d2 < r2 && c < max_nbr) ++c;
+    }
+    deg[i] = c;
+  }
+}
+
+__global__ __launch_bounds__(64) void radius_fill_kernel(const float* __restrict__ pos, const int* __restrict__ mol_ptr,
+                                                         float r2, int max_nbr, const int* __restrict__ row_ptr,
+                                                         int* __restrict__ src, int* __restrict__ dst) {
+  const int b = blockIdx.x;
+  const int n0 = mol_ptr[b], n1 = mol_ptr[b + 1];
+  for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
+    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    int c = 0;
+    const int base = row_ptr[i];
+    for (int j = n0; j < n1; ++j) {
+      const float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      if (j != i && d2 < r2 && c < max_nbr) {
+        src[base + c] = j;
+        dst[base + c] = i;
+        ++c;
+      }
+    }
+  }
+}
+
+// raw (norm-normalised) real spherical harmonics l = 2 and their gradients wrt the unit vector
+struct SH2 {
+  float v[5];
+  float g[5][3];
+};
+__device__ __forceinline__ SH2 sh2_of(float x, float y, float z) {
+  const float s3 = 1.7320508075688772f;
+  SH2 s;
+  s.v[0] = s3 * x * z, s.g[0][0] = s3 * z, s.g[0][1] = 0.f, s.g[0][2] = s3 * x;
+  s.v[1] = s3 * x * y, s.g[1][0] = s3 * y, s.g[1][1] = s3 * x, s.g[1][2] = 0.f;
+  s.v[2] = y * y - 0.5f * (x * x + z * z), s.g[2][0] = -x, s.g[2][1] = 2.f * y, s.g[2][2] = -z;
+  s.v[3] = s3 * y * z, s.g[3][0] = 0.f, s.g[3][1] = s3 * z, s.g[3][2] = s3 * y;
+  s.v[4] = 0.5f * s3 * (z * z - x * x), s.g[4][0] = -s3 * x, s.g[4][1] = 0.f, s.g[4][2] = s3 * z;
+  return s;
+}
+
+__global__ __launch_bounds__(256) void edge_geom_fwd_kernel(const float* __restrict__ pos, const int* __restrict__ src,
+                                                            const int* __restrict__ dst,
+                                                            const float* __restrict__ offsets, int E, int lmax,
+                                                            float* __restrict__ vec, float* __restrict__ len,
+                                                            float* __restrict__ sh) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int s = src[e], d = dst[e];
+  float vx = pos[3 * s] - pos[3 * d], vy = pos[3 * s + 1] - pos[3 * d + 1], vz = pos[3 * s + 2] - pos[3 * d + 2];
+  if (offsets) vx += offsets[3 * e], vy += offsets[3 * e + 1], vz += offsets[3 * e + 2];
+  vec[3 * e] = vx, vec[3 * e + 1] = vy, vec[3 * e + 2] = vz;
+  const float L = sqrtf(vx * vx + vy * vy + vz * vz);
+  len[e] = L;
+  const float inv = 1.f / fmaxf(L, 1e-12f);
+  const float x = vx * inv, y = vy * inv, z = vz * inv;
+  const int S = (lmax + 1) * (lmax + 1);
+  float* o = sh + (long)e * S;
+  o[0] = 1.f;
+  if (lmax >= 1) {
+    const float c1 = 1.7320508075688772f;
+    o[1] = c1 * x, o[2] = c1 * y, o[3] = c1 * z;
+  }
+  if (lmax >= 2) {
+    const float c2 = 2.23606797749979f;
+    const SH2 s2 = sh2_of(x, y, z);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o[4 + i] = c2 * s2.v[i];
+    if (lmax >= 3) {
+      const float c3 = 2.6457513110645907f;
+      const float y2 = y * y, x2z2 = x * x + z * z;
+      const float a = 0.9128709291752769f /* sqrt(5/6) */, b5 = 2.23606797749979f, c38 = 0.6123724356957945f;
+      o[9] = c3 * a * (s2.v[0] * z + s2.v[4] * x);
+      o[10] = c3 * b5 * s2.v[0] * y;
+      o[11] = c3 * c38 * (4.f * y2 - x2z2) * x;
+      o[12] = c3 * 0.5f * y * (2.f * y2 - 3.f * x2z2);
+      o[13] = c3 * c38 * z * (4.f * y2 - x2z2);
+      o[14] = c3 * b5 * s2.v[4] * y;
+      o[15] = c3 * a * (s2.v[4] * z - s2.v[0] * x);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void edge_geom_bwd_kernel(const float* __restrict__ vec, const float* __restrict__ d_sh,
+                                                            const float* __restrict__ d_len, int E, int lmax,
+                                                            float* __restrict__ d_vec) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float vx = vec[3 * e], vy = vec[3 * e + 1], vz = vec[3 * e + 2];
+  const float L = sqrtf(vx * vx + vy * vy + vz * vz);
+  const float inv = 1.f / fmaxf(L, 1e-12f);
+  const float x = vx * inv, y = vy * inv, z = vz * inv;
+  float gx = 0.f, gy = 0.f, gz = 0.f;  // gradient wrt the unit vector
+  if (d_sh) {
+    const int S = (lmax + 1) * (lmax + 1);
+    const float* g = d_sh + (long)e * S;
+    if (lmax >= 1) {
+      const float c1 = 1.7320508075688772f;
+      gx += c1 * g[1], gy += c1 * g[2], gz += c1 * g[3];
+    }
+    if (lmax >= 2) {
+      const float c2 = 2.23606797749979f;
+      const SH2 s2 = sh2_of(x, y, z);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const float t = c2 * g[4 + i];
+        gx += t * s2.g[i][0], gy += t * s2.g[i][1], gz += t * s2.g[i][2];
+      }
+      if (lmax >= 3) {
+        const float c3 = 2.6457513110645907f;
+        const float y2 = y * y, x2z2 = x * x + z * z;
+        const float a = 0.9128709291752769f, b5 = 2.23606797749979f, c38 = 0.6123724356957945f;
+        const float q = 4.f * y2 - x2z2;
+        float t;
+        // t0 = a (s0 z + s4 x)
+        t = c3 * a * g[9];
+        gx += t * (s2.g[0][0] * z + s2.g[4][0] * x + s2.v[4]);
+        gy += t * (s2.g[0][1] * z + s2.g[4][1] * x);
+        gz += t * (s2.g[0][2] * z + s2.v[0] + s2.g[4][2] * x);
+        // t1 = sqrt5 s0 y
+        t = c3 * b5 * g[10];
+        gx += t * s2.g[0][0] * y, gy += t * (s2.g[0][1] * y + s2.v[0]), gz += t * s2.g[0][2] * y;
+        // t2 = c38 q x
+        t = c3 * c38 * g[11];
+        gx += t * (q - 2.f * x * x), gy += t * (8.f * y * x), gz += t * (-2.f * z * x);
+        // t3 = .5 y (2 y2 - 3 x2z2)
+        t = c3 * 0.5f * g[12];
+        gx += t * (-6.f * x * y), gy += t * (2.f * y2 - 3.f * x2z2 + 4.f * y2), gz += t * (-6.f * z * y);
+        // t4 = c38 z q
+        t = c3 * c38 * g[13];
+        gx += t * (-2.f * x * z), gy += t * (8.f * y * z), gz += t * (q - 2.f * z * z);
+        // t5 = sqrt5 s4 y
+        t = c3 * b5 * g[14];
+        gx += t * s2.g[4][0] * y, gy += t * (s2.g[4][1] * y + s2.v[4]), gz += t * s2.g[4][2] * y;
+        // t6 = a (s4 z - s0 x)
+        t = c3 * a * g[15];
+        gx += t * (s2.g[4][0] * z - s2.g[0][0] * x - s2.v[0]);
+        gy += t * (s2.g[4][1] * z - s2.g[0][1] * x);
+        gz += t * (s2.g[4][2] * z + s2.v[4] - s2.g[0][2] * x);
+      }
+    }
+  }
+  // d unit / d vec = (I - u u^T) / L
+  const float ug = x * gx + y * gy + z * gz;
+  float ox = (gx - x * ug) * inv, oy = (gy - y * ug) * inv, oz = (gz - z * ug) * inv;
+  if (d_len) {
+    const float gl = d_len[e];
+    ox += gl * x, oy += gl * y, oz += gl * z;
+  }
+  d_vec[3 * e] = ox, d_vec[3 * e + 1] = oy, d_vec[3 * e + 2] = oz;
+}
+
+// ---------------------------------------------------------------------------------------------- radial basis
+constexpr float kGaussA = 2.5066272160016134f;  // sqrt(2 * 3.14159), the reference's truncated pi
+
+__global__ __launch_bounds__(256) void rbf_gauss_fwd_kernel(const float* __restrict__ len, long total, int R,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ stdp,
+                                                            const float* __restrict__ weight,
+                                                            const float* __restrict__ bias, float inv_cut,
+                                                            float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long e = idx / R;
+  const int r = (int)(idx - e * R);
+  const float x = weight[0] * (len[e] * inv_cut) + bias[0];
+  const float sd = fabsf(stdp[r]) + 1e-5f;
+  const float t = (x - mean[r]) / sd;
+  out[idx] = __expf(-0.5f * t * t) / (kGaussA * sd);
+}
+
+// thread r reduces CH edges for d_mean[r], d_std[r]; d_weight / d_bias reduced over the block
+__global__ __launch_bounds__(256) void rbf_gauss_bwd_kernel(const float* __restrict__ len, const float* __restrict__ g,
+                                                            int E, int R, const float* __restrict__ mean,
+                                                            const float* __restrict__ stdp,
+                                                            const float* __restrict__ weight,
+                                                            const float* __restrict__ bias, float inv_cut,
+                                                            float* __restrict__ d_mean, float* __restrict__ d_std,
+                                                            float* __restrict__ d_weight, float* __restrict__ d_bias,
+                                                            int CH) {
+  const int r = threadIdx.x;
+  const int e0 = blockIdx.x * CH, e1 = min(E, e0 + CH);
+  float am = 0.f, as = 0.f, aw = 0.f, ab = 0.f;
+  if (r < R) {
+    const float w = weight[0], b = bias[0], mu = mean[r], sp = stdp[r];
+    const float sd = fabsf(sp) + 1e-5f, sgn = (sp >= 0.f) ? 1.f : -1.f;
+    for (int e = e0; e < e1; ++e) {
+      const float xs = len[e] * inv_cut;
+      const float t = (w * xs + b - mu) / sd;
+      const float o = __expf(-0.5f * t * t) / (kGaussA * sd);
+      const float go = g[(long)e * R + r] * o;
+      const float dxv = -go * t / sd;
+      am -= dxv;
+      as += go * (t * t - 1.f) / sd * sgn;
+      aw += dxv * xs;
+      ab += dxv;
+    }
+    atomicAdd(d_mean + r, am);
+    atomicAdd(d_std + r, as);
+  }
+  __shared__ float rw[4], rb[4];
+  aw = wave_sum(aw), ab = wave_sum(ab);
+  if ((threadIdx.x & 63) == 0) rw[threadIdx.x >> 6] = aw, rb[threadIdx.x >> 6] = ab;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, c = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) a += rw[i], c += rb[i];
+    atomicAdd(d_weight, a);
+    atomicAdd(d_bias, c);
+  }
+}
+
+// one wavefront per edge: d_len[e] = sum_r g * d out / d len
+__global__ __launch_bounds__(256) void rbf_gauss_dlen_kernel(const float* __restrict__ len, const float* __restrict__ g,
+                                                             int E, int R, const float* __restrict__ mean,
+                                                             const float* __restrict__ stdp,
+                                                             const float* __restrict__ weight,
+                                                             const float* __restrict__ bias, float inv_cut,
+                                                             float* __restrict__ d_len) {
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= E) return;
+  const float w = weight[0], x = w * (len[e] * inv_cut) + bias[0];
+  float acc = 0.f;
+  for (int r = lane; r < R; r += 64) {
+    const float sd = fabsf(stdp[r]) + 1e-5f;
+    const float t = (x - mean[r]) / sd;
+    const float o = __expf(-0.5f * t * t) / (kGaussA * sd);
+    acc += g[(long)e * R + r] * (-o * t / sd);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) d_len[e] = acc * w * inv_cut;
+}
+
+__global__ __launch_bounds__(256) void rbf_expnorm_fwd_kernel(const float* __restrict__ len, long total, int R,
+                                                              const float* __restrict__ means,
+                                                              const float* __restrict__ betas, float alpha, float rc,
+                                                              float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long e = idx / R;
+  const int r = (int)(idx - e * R);
+  const float d = len[e];
+  const float cut = (d < rc) ? 0.5f * (cosf(d * 3.14159265358979323846f / rc) + 1.f) : 0.f;
+  const float q = expf(-alpha * d) - means[r];
+  out[idx] = cut * expf(-betas[r] * q * q);
+}
+
+__global__ __launch_bounds__(256) void rbf_expnorm_dlen_kernel(const float* __restrict__ len, const float* __restrict__ g,
+                                                               int E, int R, const float* __restrict__ means,
+                                                               const float* __restrict__ betas, float alpha, float rc,
+                                                               float* __restrict__ d_len) {
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= E) return;
+  const float d = len[e];
+  const float pi = 3.14159265358979323846f;
+  const bool in = d < rc;
+  const float cut = in ? 0.5f * (cosf(d * pi / rc) + 1.f) : 0.f;
+  const float dcut = in ? -0.5f * sinf(d * pi / rc) * pi / rc : 0.f;
+  const float ex = expf(-alpha * d);
+  float acc = 0.f;
+  for (int r = lane; r < R; r += 64) {
+    const float q = ex - means[r];
+    const float En = expf(-betas[r] * q * q);
+    acc += g[(long)e * R + r] * (dcut * En + cut * En * (-2.f * betas[r] * q) * (-alpha * ex));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) d_len[e] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eqf_radius_graph_count(const float* pos, const int* mol_ptr, int n_mol, float r, int max_nbr, int* deg,
+                           void* stream) {
+  if (!pos || !mol_ptr || !deg || max_nbr < 1) return EQF_E_BADARG;
+  if (n_mol <= 0) return 0;
+  hipLaunchKernelGGL(radius_count_kernel, dim3(n_mol), dim3(64), 0, (hipStream_t)stream, pos, mol_ptr, r * r, max_nbr,
+                     deg);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_radius_graph_fill(const float* pos, const int* mol_ptr, int n_mol, float r, int max_nbr, const int* row_ptr,
+                          int* src, int* dst, void* stream) {
+  if (!pos || !mol_ptr || !row_ptr || !src || !dst || max_nbr < 1) return EQF_E_BADARG;
+  if (n_mol <= 0) return 0;
+  hipLaunchKernelGGL(radius_fill_kernel, dim3(n_mol), dim3(64), 0, (hipStream_t)stream, pos, mol_ptr, r * r, max_nbr,
+                     row_ptr, src, dst);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_edge_geom_fwd(const float* pos, const int* src, const int* dst, const float* offsets, int E, int lmax,
+                      float* vec, float* len, float* sh, void* stream) {
+  if (!pos || !src || !dst || !vec || !len || !sh) return EQF_E_BADARG;
+  if (lmax < 0 || lmax > 3) return EQF_E_UNSUPPORTED;
+  if (E <= 0) return 0;
+  hipLaunchKernelGGL(edge_geom_fwd_kernel, dim3(eqf_cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, pos, src, dst,
+                     offsets, E, lmax, vec, len, sh);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_edge_geom_bwd(const float* vec, const float* d_sh, const float* d_len, int E, int lmax, float* d_vec,
+                      void* stream) {
+  if (!vec || !d_vec) return EQF_E_BADARG;
+  if (lmax < 0 || lmax > 3) return EQF_E_UNSUPPORTED;
+  if (E <= 0) return 0;
+  hipLaunchKernelGGL(edge_geom_bwd_kernel, dim3(eqf_cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, vec, d_sh, d_len,
+                     E, lmax, d_vec);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_rbf_gaussian_fwd(const float* len, int E, int R, const float* mean, const float* std, const float* weight,
+                         const float* bias, float cutoff, float* out, void* stream) {
+  if (!len || !mean || !std || !weight || !bias || !out || R < 1) return EQF_E_BADARG;
+  if (E <= 0) return 0;
+  const long total = (long)E * R;
+  hipLaunchKernelGGL(rbf_gauss_fwd_kernel, dim3(eqf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, len, total, R,
+                     mean, std, weight, bias, 1.f / cutoff, out);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_rbf_gaussian_bwd(const float* len, const float* d_out, int E, int R, const float* mean, const float* std,
+                         const float* weight, const float* bias, float cutoff, float* d_mean, float* d_std,
+                         float* d_weight, float* d_bias, float* d_len, void* stream) {
+  if (!len || !d_out || !mean || !std || !weight || !bias || !d_mean || !d_std || !d_weight || !d_bias)
+    return EQF_E_BADARG;
+  if (R > 256) return EQF_E_UNSUPPORTED;
+  if (E <= 0) return 0;
+  const int CH = 64;
+  const int threads = ((R + 63) / 64) * 64;
+  hipLaunchKernelGGL(rbf_gauss_bwd_kernel, dim3(eqf_cdiv(E, CH)), dim3(threads), 0, (hipStream_t)stream, len, d_out, E,
+                     R, mean, std, weight, bias, 1.f / cutoff, d_mean, d_std, d_weight, d_bias, CH);
+  EQF_CHECK_LAUNCH();
+  if (d_len) {
+    hipLaunchKernelGGL(rbf_gauss_dlen_kernel, dim3(eqf_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, len, d_out, E, R,
+                       mean, std, weight, bias, 1.f / cutoff, d_len);
+    EQF_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int eqf_rbf_expnorm_fwd(const float* len, int E, int R, const float* means, const float* betas, float alpha,
+                        float cutoff, float* out, void* stream) {
+  if (!len || !means || !betas || !out || R < 1) return EQF_E_BADARG;
+  if (E <= 0) return 0;
+  const long total = (long)E * R;
+  hipLaunchKernelGGL(rbf_expnorm_fwd_kernel, dim3(eqf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, len, total,
+                     R, means, betas, alpha, cutoff, out);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_rbf_expnorm_bwd(const float* len, const float* d_out, int E, int R, const float* means, const float* betas,
+                        float alpha, float cutoff, float* d_len, void* stream) {
+  if (!len || !d_out || !means || !betas || !d_len) return EQF_E_BADARG;
+  if (E <= 0) return 0;
+  hipLaunchKernelGGL(rbf_expnorm_dlen_kernel, dim3(eqf_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, len, d_out, E, R,
+                     means, betas, alpha, cutoff, d_len);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

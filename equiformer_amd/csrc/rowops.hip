@@ -1,0 +1,484 @@
+// Row-local feature ops of the Equiformer hot path (HBM-bound): equivariant layer norm, gate / SiLU
+// activations, the radial MLP's LayerNorm+SiLU, atom-type embedding and column sums (bias gradients).
+// One wavefront (64 lanes) owns one row; rows are 0.25-3.5 KB, so a row is read once into L1/registers
+// and written once -- algorithmic traffic = 2 x rows x D x 4 bytes.
+#include "common.h"
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+struct SegTab {
+  int nseg;
+  int off[EQF_MAX_SEG];   // row offset
+  int len[EQF_MAX_SEG];   // mul * (2l+1)
+  int mul[EQF_MAX_SEG];
+  int l[EQF_MAX_SEG];
+  int woff[EQF_MAX_SEG];  // offset into affine_weight
+  int boff[EQF_MAX_SEG];  // offset into affine_bias (l == 0 only, else -1)
+  int D;
+};
+
+SegTab make_segtab(const eqf_irreps& ir) {
+  SegTab t{};
+  t.nseg = ir.nseg;
+  int off = 0, w = 0, b = 0;
+  for (int s = 0; s < ir.nseg; ++s) {
+    t.off[s] = off;
+    t.mul[s] = ir.mul[s];
+    t.l[s] = ir.l[s];
+    t.len[s] = ir.mul[s] * (2 * ir.l[s] + 1);
+    t.woff[s] = w;
+    t.boff[s] = (ir.l[s] == 0) ? b : -1;
+    w += ir.mul[s];
+    if (ir.l[s] == 0) b += ir.mul[s];
+    off += t.len[s];
+  }
+  t.D = off;
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------- layer norm
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            float* __restrict__ rstd, float* __restrict__ mean0,
+                                                            int rows, SegTab T, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * T.D;
+  float* yr = y + (long)row * T.D;
+  bool first0 = true;
+  for (int s = 0; s < T.nseg; ++s) {
+    const float* xs = xr + T.off[s];
+    const int n = T.len[s], mul = T.mul[s];
+    float mean = 0.f;
+    if (T.l[s] == 0) {
+      float sum = 0.f;
+      for (int i = lane; i < n; i += 64) sum += xs[i];
+      mean = wave_sum(sum) / n;
+    }
+    float sq = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      const float v = xs[i] - mean;
+      sq += v * v;
+    }
+    const float rs = rsqrtf(wave_sum(sq) / n + eps);
+    if (lane == 0) {
+      rstd[(long)row * T.nseg + s] = rs;
+      if (T.l[s] == 0 && first0) mean0[row] = mean;
+    }
+    if (T.l[s] == 0) first0 = false;
+    const float* ws = w + T.woff[s];
+    for (int i = lane; i < n; i += 64) {
+      const int u = i % mul;
+      float v = (xs[i] - mean) * rs * ws[u];
+      if (T.boff[s] >= 0) v += b[T.boff[s] + u];
+      yr[T.off[s] + i] = v;
+    }
+  }
+}
+
+// dx only; affine-parameter gradients are column reductions done by layernorm_wgrad_kernel
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ dy, const float* __restrict__ rstd,
+                                                            float* __restrict__ dx, int rows, SegTab T) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * T.D;
+  const float* gr = dy + (long)row * T.D;
+  float* dr = dx + (long)row * T.D;
+  for (int s = 0; s < T.nseg; ++s) {
+    const float* xs = xr + T.off[s];
+    const float* gs = gr + T.off[s];
+    const float* ws = w + T.woff[s];
+    const int n = T.len[s], mul = T.mul[s];
+    const float rs = rstd[(long)row * T.nseg + s];
+    float mean = 0.f;
+    if (T.l[s] == 0) {
+      float sum = 0.f;
+      for (int i = lane; i < n; i += 64) sum += xs[i];
+      mean = wave_sum(sum) / n;
+    }
+    float sg = 0.f, sgx = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      const float g = gs[i] * ws[i % mul];
+      const float xh = (xs[i] - mean) * rs;
+      sg += g;
+      sgx += g * xh;
+    }
+    sgx = wave_sum(sgx) / n;
+    sg = (T.l[s] == 0) ? wave_sum(sg) / n : 0.f;
+    for (int i = lane; i < n; i += 64) {
+      const float g = gs[i] * ws[i % mul];
+      const float xh = (xs[i] - mean) * rs;
+      dr[T.off[s] + i] = rs * (g - sg - xh * sgx);
+    }
+  }
+}
+
+// d_weight[woff+u] += sum_rows sum_m dy*xhat ; d_bias[boff+u] += sum_rows dy.   One thread per row column,
+// each block reduces CH rows, atomics at the end (columns of the same channel collide only (2l+1) ways).
+__global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ rstd,
+                                                              const float* __restrict__ mean0, float* __restrict__ dw,
+                                                              float* __restrict__ db, int rows, SegTab T, int CH) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= T.D) return;
+  int s = 0;
+  while (s + 1 < T.nseg && c >= T.off[s + 1]) ++s;
+  const int u = (c - T.off[s]) % T.mul[s];
+  const int r0 = blockIdx.y * CH, r1 = min(rows, r0 + CH);
+  const bool is0 = T.l[s] == 0;
+  float aw = 0.f, ab = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float g = dy[(long)r * T.D + c];
+    float xv = x[(long)r * T.D + c];
+    if (is0) {
+      // mean0 holds the mean of the first 0e segment; other 0e segments (none in practice) recompute
+      xv -= mean0[r];
+    }
+    aw += g * xv * rstd[(long)r * T.nseg + s];
+    ab += g;
+  }
+  atomicAdd(dw + T.woff[s] + u, aw);
+  if (T.boff[s] >= 0) atomicAdd(db + T.boff[s] + u, ab);
+}
+
+// ---------------------------------------------------------------------------------------------- gate
+struct GateTab {
+  int S, G, nseg;
+  int in_off[EQF_MAX_SEG], out_off[EQF_MAX_SEG], goff[EQF_MAX_SEG], mul[EQF_MAX_SEG], d[EQF_MAX_SEG];
+  int Din, Dout;
+};
+
+GateTab make_gatetab(int S, const eqf_irreps& gated) {
+  GateTab t{};
+  t.S = S;
+  t.nseg = gated.nseg;
+  int G = 0;
+  for (int s = 0; s < gated.nseg; ++s) G += gated.mul[s];
+  t.G = G;
+  int in_off = S + G, out_off = S, g = 0;
+  for (int s = 0; s < gated.nseg; ++s) {
+    t.in_off[s] = in_off, t.out_off[s] = out_off, t.goff[s] = S + g;
+    t.mul[s] = gated.mul[s], t.d[s] = 2 * gated.l[s] + 1;
+    in_off += t.mul[s] * t.d[s], out_off += t.mul[s] * t.d[s], g += t.mul[s];
+  }
+  t.Din = in_off, t.Dout = out_off;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long total,
+                                                       GateTab T, float c_silu, float c_sig) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long row = idx / T.Dout;
+  const int c = (int)(idx - row * T.Dout);
+  const float* ir = in + row * T.Din;
+  float v;
+  if (c < T.S) {
+    const float s = ir[c];
+    v = c_silu * s * sigmoidf_(s);
+  } else {
+    int sg = 0;
+    while (sg + 1 < T.nseg && c >= T.out_off[sg + 1]) ++sg;
+    const int j = c - T.out_off[sg];
+    const int u = j % T.mul[sg];
+    v = ir[T.in_off[sg] + j] * c_sig * sigmoidf_(ir[T.goff[sg] + u]);
+  }
+  out[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ in, const float* __restrict__ d_out,
+                                                       float* __restrict__ d_in, long total, GateTab T, float c_silu,
+                                                       float c_sig) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per INPUT element
+  if (idx >= total) return;
+  const long row = idx / T.Din;
+  const int c = (int)(idx - row * T.Din);
+  const float* ir = in + row * T.Din;
+  const float* gr = d_out + row * T.Dout;
+  float v;
+  if (c < T.S) {
+    const float s = ir[c], sg = sigmoidf_(s);
+    v = gr[c] * c_silu * (sg + s * sg * (1.f - sg));
+  } else if (c < T.S + T.G) {
+    int sg = 0;
+    while (sg + 1 < T.nseg && c >= T.goff[sg + 1]) ++sg;
+    const int u = c - T.goff[sg];
+    const float gsig = sigmoidf_(ir[c]);
+    float acc = 0.f;
+    for (int m = 0; m < T.d[sg]; ++m) acc += gr[T.out_off[sg] + m * T.mul[sg] + u] * ir[T.in_off[sg] + m * T.mul[sg] + u];
+    v = acc * c_sig * gsig * (1.f - gsig);
+  } else {
+    int sg = 0;
+    while (sg + 1 < T.nseg && c >= T.in_off[sg + 1]) ++sg;
+    const int j = c - T.in_off[sg];
+    const int u = j % T.mul[sg];
+    v = gr[T.out_off[sg] + j] * c_sig * sigmoidf_(ir[T.goff[sg] + u]);
+  }
+  d_in[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------- silu
+__global__ __launch_bounds__(256) void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n4,
+                                                       long n, float c) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x = c * v.x * sigmoidf_(v.x), v.y = c * v.y * sigmoidf_(v.y);
+    v.z = c * v.z * sigmoidf_(v.z), v.w = c * v.w * sigmoidf_(v.w);
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+  if (i == 0)
+    for (long j = n4 * 4; j < n; ++j) y[j] = c * x[j] * sigmoidf_(x[j]);
+}
+
+__device__ __forceinline__ float dsilu(float s) {
+  const float sg = sigmoidf_(s);
+  return sg + s * sg * (1.f - sg);
+}
+
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, long n4, long n, float c) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    float4 o;
+    o.x = c * g.x * dsilu(v.x), o.y = c * g.y * dsilu(v.y), o.z = c * g.z * dsilu(v.z), o.w = c * g.w * dsilu(v.w);
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+  if (i == 0)
+    for (long j = n4 * 4; j < n; ++j) dx[j] = c * dy[j] * dsilu(x[j]);
+}
+
+// ---------------------------------------------------------------------------------------------- LN(C<=64) + SiLU
+__global__ __launch_bounds__(256) void lnsilu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y, int rows,
+                                                         int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bool act = lane < C;
+  const float v = act ? x[(long)row * C + lane] : 0.f;
+  const float mean = wave_sum(v) / C;
+  const float d = act ? v - mean : 0.f;
+  const float rs = rsqrtf(wave_sum(d * d) / C + eps);
+  if (act) {
+    const float z = d * rs * gamma[lane] + beta[lane];
+    y[(long)row * C + lane] = z * sigmoidf_(z);
+  }
+}
+
+__global__ __launch_bounds__(256) void lnsilu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, float* __restrict__ d_gamma,
+                                                         float* __restrict__ d_beta, int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * WAVES_PER_BLOCK;
+  const bool act = lane < C;
+  const float gm = act ? gamma[lane] : 0.f, bt = act ? beta[lane] : 0.f;
+  float acc_g = 0.f, acc_b = 0.f;
+  for (int row = wave_global; row < rows; row += nwaves) {
+    const float v = act ? x[(long)row * C + lane] : 0.f;
+    const float mean = wave_sum(v) / C;
+    const float d = act ? v - mean : 0.f;
+    const float rs = rsqrtf(wave_sum(d * d) / C + eps);
+    const float xh = d * rs;
+    const float z = xh * gm + bt;
+    const float dz = act ? dy[(long)row * C + lane] * dsilu(z) : 0.f;
+    acc_g += dz * xh;
+    acc_b += dz;
+    const float g = dz * gm;
+    const float sg = wave_sum(g) / C;
+    const float sgx = wave_sum(g * xh) / C;
+    if (act) dx[(long)row * C + lane] = rs * (g - sg - xh * sgx);
+  }
+  __shared__ float red_g[WAVES_PER_BLOCK][64], red_b[WAVES_PER_BLOCK][64];
+  red_g[threadIdx.x >> 6][lane] = acc_g;
+  red_b[threadIdx.x >> 6][lane] = acc_b;
+  __syncthreads();
+  if (threadIdx.x < 64 && threadIdx.x < C) {
+    float a = 0.f, b = 0.f;
+    for (int wv = 0; wv < WAVES_PER_BLOCK; ++wv) a += red_g[wv][threadIdx.x], b += red_b[wv][threadIdx.x];
+    atomicAdd(d_gamma + threadIdx.x, a);
+    atomicAdd(d_beta + threadIdx.x, b);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ type, const float* __restrict__ W,
+                                                        const float* __restrict__ b, float* __restrict__ y, long total,
+                                                        int C, int D) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long row = idx / D;
+  const int c = (int)(idx - row * D);
+  y[idx] = (c < C) ? W[(long)type[row] * C + c] + (b ? b[c] : 0.f) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ type, const float* __restrict__ dy,
+                                                        float* __restrict__ dW, float* __restrict__ db, int rows, int C,
+                                                        int D, int CH) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * CH, r1 = min(rows, r0 + CH);
+  float ab = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float g = dy[(long)r * D + c];
+    ab += g;
+    atomicAdd(dW + (long)type[r] * C + c, g);
+  }
+  if (db) atomicAdd(db + c, ab);
+}
+
+// ---------------------------------------------------------------------------------------------- column sum
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int d, int ld, int inner, int R, int N,
+                                                     float* __restrict__ out, int CH) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const int r0 = blockIdx.y * CH, r1 = min(R, r0 + CH);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += X[row_off2(r, d, ld, inner) + c];
+  atomicAdd(out + c, acc);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* eqf_version(void) { return "equiformer_hip 0.1 gfx950"; }
+
+int eqf_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd, float* mean0,
+                      int rows, const eqf_irreps* irreps, float eps, void* stream) {
+  if (!x || !weight || !bias || !y || !rstd || !mean0 || !irreps || irreps->nseg < 1 || irreps->nseg > EQF_MAX_SEG)
+    return EQF_E_BADARG;
+  if (rows <= 0) return 0;
+  const SegTab T = make_segtab(*irreps);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, x,
+                     weight, bias, y, rstd, mean0, rows, T, eps);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_layernorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd, const float* mean0,
+                      float* dx, float* d_weight, float* d_bias, int rows, const eqf_irreps* irreps, void* stream) {
+  if (!x || !weight || !dy || !rstd || !mean0 || !dx || !irreps || irreps->nseg < 1 || irreps->nseg > EQF_MAX_SEG)
+    return EQF_E_BADARG;
+  if (rows <= 0) return 0;
+  const SegTab T = make_segtab(*irreps);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, x,
+                     weight, dy, rstd, dx, rows, T);
+  EQF_CHECK_LAUNCH();
+  if (d_weight && d_bias) {
+    const int CH = 64;
+    hipLaunchKernelGGL(layernorm_wgrad_kernel, dim3(eqf_cdiv(T.D, 256), eqf_cdiv(rows, CH)), dim3(256), 0,
+                       (hipStream_t)stream, x, dy, rstd, mean0, d_weight, d_bias, rows, T, CH);
+    EQF_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int eqf_gate_fwd(const float* in, float* out, int rows, int S, const eqf_irreps* gated, float c_silu, float c_sig,
+                 void* stream) {
+  if (!in || !out || !gated) return EQF_E_BADARG;
+  if (rows <= 0) return 0;
+  const GateTab T = make_gatetab(S, *gated);
+  const long total = (long)rows * T.Dout;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(eqf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, total, T,
+                     c_silu, c_sig);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_gate_bwd(const float* in, const float* d_out, float* d_in, int rows, int S, const eqf_irreps* gated,
+                 float c_silu, float c_sig, void* stream) {
+  if (!in || !d_out || !d_in || !gated) return EQF_E_BADARG;
+  if (rows <= 0) return 0;
+  const GateTab T = make_gatetab(S, *gated);
+  const long total = (long)rows * T.Din;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(eqf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, d_out, d_in,
+                     total, T, c_silu, c_sig);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_silu_fwd(const float* x, float* y, long n, float c, void* stream) {
+  if (!x || !y) return EQF_E_BADARG;
+  if (n <= 0) return 0;
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(eqf_cdiv(n4 > 0 ? n4 : 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n4,
+                     n, c);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_silu_bwd(const float* x, const float* dy, float* dx, long n, float c, void* stream) {
+  if (!x || !dy || !dx) return EQF_E_BADARG;
+  if (n <= 0) return 0;
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(eqf_cdiv(n4 > 0 ? n4 : 1, 256)), dim3(256), 0, (hipStream_t)stream, x, dy,
+                     dx, n4, n, c);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_lnsilu_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps,
+                   void* stream) {
+  if (!x || !gamma || !beta || !y || C < 1) return EQF_E_BADARG;
+  if (C > 64) return EQF_E_UNSUPPORTED;
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(lnsilu_fwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, x,
+                     gamma, beta, y, rows, C, eps);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_lnsilu_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx, float* d_gamma,
+                   float* d_beta, int rows, int C, float eps, void* stream) {
+  if (!x || !gamma || !beta || !dy || !dx || !d_gamma || !d_beta || C < 1) return EQF_E_BADARG;
+  if (C > 64) return EQF_E_UNSUPPORTED;
+  if (rows <= 0) return 0;
+  int blocks = eqf_cdiv(rows, WAVES_PER_BLOCK * 8);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(lnsilu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy, dx,
+                     d_gamma, d_beta, rows, C, eps);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_embed_fwd(const int* type, const float* W, const float* b, float* y, int rows, int C, int D, void* stream) {
+  if (!type || !W || !y || C > D) return EQF_E_BADARG;
+  if (rows <= 0) return 0;
+  const long total = (long)rows * D;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(eqf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, type, W, b, y,
+                     total, C, D);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_embed_bwd(const int* type, const float* dy, float* dW, float* db, int rows, int C, int D, void* stream) {
+  if (!type || !dy || !dW) return EQF_E_BADARG;
+  if (rows <= 0) return 0;
+  const int CH = 64;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(eqf_cdiv(C, 256), eqf_cdiv(rows, CH)), dim3(256), 0, (hipStream_t)stream,
+                     type, dy, dW, db, rows, C, D, CH);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_colsum(const float* X, eqf_rows rx, int R, int N, float* out, void* stream) {
+  if (!X || !out || rx.d < 1) return EQF_E_BADARG;
+  if (R <= 0 || N <= 0) return 0;
+  int CH = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3(eqf_cdiv(N, 256), eqf_cdiv(R, CH)), dim3(256), 0, (hipStream_t)stream, X, rx.d,
+                     rx.ld, rx.inner, R, N, out, CH);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""ctypes binding of libequiformer_hip.so (the C ABI declared in include/equiformer_hip.h).
+
+The HIP library is THE compute path: there is no CPU or eager-PyTorch fallback.  If the shared object is missing
+or a symbol cannot be resolved this module raises at import / first use, and every entry point raises on a
+non-zero return code.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libequiformer_hip.so")
+
+EQF_MAX_SEG = 8
+EQF_MAX_PATHS = 64
+
+c_fp = ctypes.c_void_p  # device pointers travel as opaque addresses
+c_int = ctypes.c_int
+
+
+class EqfIrreps(ctypes.Structure):
+    _fields_ = [("nseg", c_int), ("l", c_int * EQF_MAX_SEG), ("mul", c_int * EQF_MAX_SEG)]
+
+
+class EqfRows(ctypes.Structure):
+    _fields_ = [("d", c_int), ("ld", c_int), ("inner", c_int)]
+
+
+_PA = c_int * EQF_MAX_PATHS
+
+
+class EqfDtpPaths(ctypes.Structure):
+    _fields_ = [("npaths", c_int), ("sh_dim", c_int), ("in_dim", c_int), ("out_dim", c_int), ("w_numel", c_int),
+                ("m_numel", c_int), ("l1", _PA), ("l2", _PA), ("l3", _PA), ("mul", _PA), ("in_off", _PA),
+                ("out_off", _PA), ("out_ch", _PA), ("out_k", _PA), ("w_off", _PA), ("cg_off", _PA), ("m_off", _PA)]
+
+
+_P_IRR = ctypes.POINTER(EqfIrreps)
+_P_PATHS = ctypes.POINTER(EqfDtpPaths)
+_PP = ctypes.POINTER(ctypes.c_void_p)
+_f = ctypes.c_float
+_u64 = ctypes.c_ulonglong
+_long = ctypes.c_long
+
+# name -> argtypes, in the order of include/equiformer_hip.h
+SIGNATURES = {
+    "eqf_radius_graph_count": [c_fp, c_fp, c_int, _f, c_int, c_fp, c_fp],
+    "eqf_radius_graph_fill": [c_fp, c_fp, c_int, _f, c_int, c_fp, c_fp, c_fp, c_fp],
+    "eqf_edge_geom_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
+    "eqf_edge_geom_bwd": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
+    "eqf_rbf_gaussian_fwd": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, _f, c_fp, c_fp],
+    "eqf_rbf_gaussian_bwd": [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "eqf_rbf_expnorm_fwd": [c_fp, c_int, c_int, c_fp, c_fp, _f, _f, c_fp, c_fp],
+    "eqf_rbf_expnorm_bwd": [c_fp, c_fp, c_int, c_int, c_fp, c_fp, _f, _f, c_fp, c_fp],
+    "eqf_gemm_nn": [c_fp, EqfRows, c_fp, c_int, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
+    "eqf_gemm_nt": [c_fp, EqfRows, c_fp, c_int, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
+    "eqf_gemm_tn": [c_fp, EqfRows, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
+    "eqf_colsum": [c_fp, EqfRows, c_int, c_int, c_fp, c_fp],
+    "eqf_dtp_coupling_fwd": [c_fp, c_fp, _P_PATHS, c_fp, c_int, c_fp],
+    "eqf_dtp_coupling_bwd": [c_fp, c_fp, _P_PATHS, c_fp, c_int, c_fp],
+    "eqf_dtp_linear_fwd": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, _P_IRR, c_int, c_fp],
+    "eqf_dtp_linear_wgrad": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, _PP, c_int, c_fp],
+    "eqf_layernorm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, _f, c_fp],
+    "eqf_layernorm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, c_fp],
+    "eqf_gate_fwd": [c_fp, c_fp, c_int, c_int, _P_IRR, _f, _f, c_fp],
+    "eqf_gate_bwd": [c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _f, c_fp],
+    "eqf_silu_fwd": [c_fp, c_fp, _long, _f, c_fp],
+    "eqf_silu_bwd": [c_fp, c_fp, c_fp, _long, _f, c_fp],
+    "eqf_lnsilu_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, _f, c_fp],
+    "eqf_lnsilu_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _f, c_fp],
+    "eqf_embed_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "eqf_embed_bwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "eqf_gather_add_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp],
+    "eqf_segment_sum": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, _f, c_int, c_fp],
+    "eqf_segment_bcast": [c_fp, c_fp, c_fp, c_int, c_int, _f, c_fp],
+    "eqf_dtp_fwd": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_int, c_fp],
+    "eqf_dtp_bwd": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, c_fp, c_fp, c_int, c_fp],
+    "eqf_alpha_fwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
+    "eqf_alpha_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
+    "eqf_attn_aggregate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp],
+    "eqf_attn_aggregate_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library and attach prototypes.  Raises HipLibraryError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            "libequiformer_hip.so not found at %s -- build it with `python -m equiformer_amd.build` "
+            "(there is no CPU fallback for the hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.eqf_version.restype = ctypes.c_char_p
+    lib.eqf_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> missing symbol, loud
+        fn.restype = c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def version():
+    return load().eqf_version().decode()
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise HipLibraryError("%s failed with code %d" % (name, rc))
+
+
+def make_irreps(segments):
+    """segments: iterable of (mul, l)."""
+    segments = list(segments)
+    if len(segments) > EQF_MAX_SEG:
+        raise ValueError("too many irreps segments")
+    s = EqfIrreps()
+    s.nseg = len(segments)
+    for i, (mul, l) in enumerate(segments):
+        s.l[i], s.mul[i] = int(l), int(mul)
+    return s

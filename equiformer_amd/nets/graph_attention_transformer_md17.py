@@ -1,0 +1,98 @@
+"""MD17 variant: energy + forces (= -dE/dpos through the HIP backward kernels).
+
+Drop-in for the reference's nets/graph_attention_transformer_md17.py (`GraphAttentionTransformerMD17` :127-327 and the
+`*_md17` factories :330-519): `forward(node_atom, pos, batch) -> (energy [B,1], forces [N,3])`, works under an outer
+`torch.no_grad()`, reads `task_mean/task_std`.
+
+Round-1 limitation: forces come from a first-order backward pass, so they carry no autograd graph
+(`create_graph=True` of the reference, nets/graph_attention_transformer_md17.py:318-325); training on the force loss
+needs the double-backward kernels that are scheduled next.
+"""
+import torch
+
+from ..graph import EdgeGraph
+from ..irreps import Irreps
+from .graph_attention_transformer import _Trunk
+from .layers import ExpNormalSmearing, GaussianRadialBasisLayer
+from .registry import register_model
+
+_MAX_ATOM_TYPE = 64
+# the reference reuses the QM9 statistics for MD17 (graph_attention_transformer_md17.py:45-48)
+_AVG_NUM_NODES = 18.03065905448718
+_AVG_DEGREE = 15.57930850982666
+
+
+class GraphAttentionTransformerMD17(_Trunk):
+    def __init__(self, irreps_in="64x0e", irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6,
+                 irreps_node_attr="1x0e", irreps_sh="1x0e+1x1e+1x2e", max_radius=5.0, number_of_basis=128,
+                 basis_type="gaussian", fc_neurons=[64, 64], irreps_feature="512x0e",
+                 irreps_head="32x0e+16x1o+8x2e", num_heads=4, irreps_pre_attn=None, rescale_degree=False,
+                 nonlinear_message=False, irreps_mlp_mid="128x0e+64x1e+32x2e", use_attn_head=False,
+                 norm_layer="layer", alpha_drop=0.2, proj_drop=0.0, out_drop=0.0, drop_path_rate=0.0, mean=None,
+                 std=None, scale=None, atomref=None):
+        super().__init__()
+        if use_attn_head:
+            raise NotImplementedError("use_attn_head=True is not used by any registered MD17 model")
+        self.use_attn_head = use_attn_head
+        self.task_mean, self.task_std, self.scale = mean, std, scale
+        self.register_buffer("atomref", atomref)
+        self.irreps_node_input = Irreps(irreps_in)
+        self.basis_type = basis_type
+        self._build_trunk(irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius,
+                          number_of_basis, fc_neurons, irreps_feature, irreps_head, num_heads, irreps_pre_attn,
+                          rescale_degree, nonlinear_message, irreps_mlp_mid, norm_layer, alpha_drop, proj_drop,
+                          out_drop, drop_path_rate, _MAX_ATOM_TYPE, _AVG_DEGREE, _AVG_NUM_NODES)
+
+    def _make_rbf(self):
+        if self.basis_type == "gaussian":
+            self.rbf = GaussianRadialBasisLayer(self.number_of_basis, cutoff=self.max_radius)
+        elif self.basis_type == "exp":
+            self.rbf = ExpNormalSmearing(cutoff_lower=0.0, cutoff_upper=self.max_radius, num_rbf=self.number_of_basis,
+                                         trainable=False)
+        elif self.basis_type == "bessel":
+            raise NotImplementedError("the 'bessel' basis needs ocpmodels' RadialBasis (un-vendored); out of scope")
+        else:
+            raise ValueError
+
+    @torch.enable_grad()
+    def forward(self, node_atom, pos, batch):
+        pos = pos.to(torch.float32).contiguous().requires_grad_(True)
+        graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=1000)
+        atom_embedding, _, _ = self.atom_embed(node_atom)
+        energy = self._trunk_forward(atom_embedding, pos, graph)
+        if self.scale is not None:
+            energy = self.scale * energy
+        keep = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        forces = -1 * torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), retain_graph=keep)[0]
+        return energy, forces
+
+
+def _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, **over):
+    kw = dict(irreps_in=irreps_in, irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6, irreps_node_attr="1x0e",
+              irreps_sh="1x0e+1x1e+1x2e", max_radius=radius, number_of_basis=num_basis, fc_neurons=[64, 64],
+              basis_type="exp", irreps_feature="512x0e", irreps_head="32x0e+16x1e+8x2e", num_heads=4,
+              irreps_pre_attn=None, rescale_degree=False, nonlinear_message=True,
+              irreps_mlp_mid="384x0e+192x1e+96x2e", norm_layer="layer", alpha_drop=0.0, proj_drop=0.0, out_drop=0.0,
+              drop_path_rate=0.0, mean=task_mean, std=task_std, scale=None, atomref=atomref)
+    kw.update(over)
+    return GraphAttentionTransformerMD17(**kw)
+
+
+@register_model
+def graph_attention_transformer_nonlinear_l2_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                  task_std=None, **kwargs):
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, basis_type="gaussian", alpha_drop=0.0)
+
+
+@register_model
+def graph_attention_transformer_nonlinear_exp_l2_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                      task_std=None, **kwargs):
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref)
+
+
+@register_model
+def graph_attention_transformer_nonlinear_exp_l3_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                      task_std=None, **kwargs):
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref,
+                 irreps_node_embedding="128x0e+64x1e+64x2e+32x3e", irreps_sh="1x0e+1x1e+1x2e+1x3e",
+                 irreps_head="32x0e+16x1e+16x2e+8x3e", irreps_mlp_mid="384x0e+192x1e+192x2e+96x3e")

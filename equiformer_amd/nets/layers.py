@@ -1,0 +1,540 @@
+"""Building blocks of the graph-attention transformer on top of the HIP operators.
+
+Module and parameter names reproduce the reference's state_dict: `*.tp.weight` (flat, e3nn
+instruction order), `*.bias.0`, `*.dtp_rad.net.{0,1,3,4,6}.*`, `*.dtp_rad.offset`, `norm_*.affine_{weight,bias}`...
+Reference sources of the semantics (paths relative to the reference root):
+  nets/tensor_product_rescale.py:15-174   TensorProductRescale / FullyConnectedTensorProductRescale / LinearRS
+  nets/fast_activation.py:15-160          Activation / Gate
+  nets/layer_norm.py:62-152               EquivariantLayerNormV2
+  nets/radial_func.py:9-49                RadialProfile
+  nets/gaussian_rbf.py:13-40              GaussianRadialBasisLayer
+  nets/graph_attention_transformer.py     DepthwiseTensorProduct :157, SeparableFCTP :186, GraphAttention :403,
+                                          FeedForwardNetwork :537, TransBlock :575, NodeEmbeddingNetwork :670,
+                                          ScaledScatter :693, EdgeDegreeEmbeddingNetwork :709
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops, so3
+from ..irreps import Irrep, Irreps
+from ..layout import DtpTable, RowLayout
+
+_RESCALE = True
+_USE_BIAS = True
+
+
+def _simplified_sorted(irreps):
+    irreps = Irreps(irreps)
+    s, _ = irreps.sort_even_first()
+    return s.simplify()
+
+
+class _TensorProductWeights(nn.Module):
+    """Stands where e3nn's `o3.TensorProduct` sits in the reference module tree (`<module>.tp`): owns the flat
+    `weight` (a Parameter when internal, an empty buffer otherwise, as e3nn registers it)."""
+
+    def __init__(self, weight_numel, internal):
+        super().__init__()
+        self.weight_numel = weight_numel
+        self.internal_weights = internal
+        if internal and weight_numel > 0:
+            self.weight = nn.Parameter(torch.randn(weight_numel))
+        else:
+            self.register_buffer("weight", torch.Tensor())
+
+
+def irreps2gate(irreps):
+    irreps = Irreps(irreps)
+    scalars = Irreps([(m, ir) for m, ir in irreps if ir.l == 0 and ir.p == 1]).simplify()
+    gated = Irreps([(m, ir) for m, ir in irreps if not (ir.l == 0 and ir.p == 1)]).simplify()
+    gates = Irreps([(m, Irrep(0, 1)) for m, _ in gated]).simplify() if gated.dim > 0 else Irreps()
+    return scalars, gates, gated
+
+
+class FullyConnectedTensorProductRescale(nn.Module):
+    """FCTP(irreps_in1 x '1x0e' -> irreps_out): with a scalar second operand every path is a per-degree dense
+    channel mix out_l = x_l W_l (+ bias on 0e), executed as MFMA GEMMs on the l-segments of the rows."""
+
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, bias=True, rescale=True, internal_weights=None,
+                 shared_weights=None, normalization=None):
+        super().__init__()
+        self.irreps_in1 = Irreps(irreps_in1)
+        self.irreps_in2 = Irreps(irreps_in2)
+        self.irreps_out = Irreps(irreps_out)
+        if self.irreps_in2 != Irreps("1x0e"):
+            raise NotImplementedError("only scalar node attributes ('1x0e') are supported, got %r" % self.irreps_in2)
+        self.rescale, self.use_bias = rescale, bias
+        self.layout_in = RowLayout(self.irreps_in1) if self._is_layout(self.irreps_in1) else RowLayout(
+            self.irreps_in1.simplify())
+        self.layout_out = RowLayout(self.irreps_out.simplify())
+        self.spec = ops.LinearSpec(self.layout_in, self.layout_out)
+        self.tp = _TensorProductWeights(self.spec.weight_numel, True)
+        biases = []
+        if bias and self.spec.bias_dim > 0:
+            biases.append(nn.Parameter(torch.zeros(self.spec.bias_dim)))
+        self.bias = nn.ParameterList(biases)
+        if rescale:
+            with torch.no_grad():
+                for (l, _, K, _, N, w_off) in self.spec.pairs:
+                    self.tp.weight[w_off:w_off + K * N].mul_(1.0 / math.sqrt(K))
+
+    @staticmethod
+    def _is_layout(irreps):
+        ls = [ir.l for _, ir in irreps]
+        return ls == sorted(set(ls))
+
+    def _bias(self):
+        return self.bias[0] if len(self.bias) > 0 else None
+
+    def forward_tp_rescale_bias(self, x, y=None, weight=None):
+        return ops.irreps_linear(x, self.tp.weight, self._bias(), self.spec)
+
+    def forward(self, x, y=None, weight=None):
+        return self.forward_tp_rescale_bias(x, y, weight)
+
+
+class LinearRS(FullyConnectedTensorProductRescale):
+    def __init__(self, irreps_in, irreps_out, bias=True, rescale=True):
+        super().__init__(irreps_in, Irreps("1x0e"), irreps_out, bias=bias, rescale=rescale, internal_weights=True,
+                         shared_weights=True)
+
+    def forward(self, x):
+        return self.forward_tp_rescale_bias(x)
+
+
+class Activation(nn.Module):
+    """Second-moment-normalised scalar activation applied to a whole 0e tensor (fast_activation.py:68-71)."""
+
+    def __init__(self, irreps_in, acts=None, kind="silu"):
+        super().__init__()
+        self.irreps_in = self.irreps_out = Irreps(irreps_in)
+        assert all(ir.l == 0 for _, ir in self.irreps_in)
+        self.kind = kind
+        self.cst = {"silu": so3.C_SILU}[kind]
+
+    def forward(self, x):
+        return ops.scaled_silu(x, self.cst)
+
+
+class Gate(nn.Module):
+    def __init__(self, irreps_scalars, irreps_gates, irreps_gated):
+        super().__init__()
+        self.irreps_scalars, self.irreps_gates, self.irreps_gated = irreps_scalars, irreps_gates, irreps_gated
+        self._irreps_in = (irreps_scalars + irreps_gates + irreps_gated).simplify()
+        self._irreps_out = (irreps_scalars + irreps_gated).simplify()
+        self.S = irreps_scalars.dim
+        self.gated_layout = RowLayout(irreps_gated)
+
+    @property
+    def irreps_in(self):
+        return self._irreps_in
+
+    @property
+    def irreps_out(self):
+        return self._irreps_out
+
+    def forward(self, x):
+        return ops.gate(x, self.S, self.gated_layout, so3.C_SILU, so3.C_SIGMOID)
+
+
+def make_gate(irreps_out):
+    scalars, gates, gated = irreps2gate(irreps_out)
+    if gated.num_irreps == 0:
+        return Activation(irreps_out, kind="silu")
+    return Gate(scalars, gates, gated)
+
+
+class FullyConnectedTensorProductRescaleSwishGate(FullyConnectedTensorProductRescale):
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, bias=True, rescale=True, internal_weights=None,
+                 shared_weights=None, normalization=None):
+        gate = make_gate(irreps_out)
+        super().__init__(irreps_in1, irreps_in2, gate.irreps_in, bias=bias, rescale=rescale)
+        self.gate = gate
+
+    def forward(self, x, y=None, weight=None):
+        return self.gate(self.forward_tp_rescale_bias(x, y, weight))
+
+
+class EquivariantLayerNormV2(nn.Module):
+    def __init__(self, irreps, eps=1e-5, affine=True, normalization="component"):
+        super().__init__()
+        assert affine and normalization == "component"
+        self.irreps = Irreps(irreps)
+        self.layout = RowLayout(self.irreps.simplify())
+        self.eps = eps
+        self.affine_weight = nn.Parameter(torch.ones(self.irreps.num_irreps))
+        self.affine_bias = nn.Parameter(torch.zeros(sum(m for m, ir in self.irreps if ir.l == 0 and ir.p == 1)))
+
+    def forward(self, node_input, **kwargs):
+        if node_input.shape[-1] != self.layout.dim:
+            raise AssertionError("`ix` should have reached node_input.size(-1) ({}), but it ended at {}".format(
+                node_input.shape[-1], self.layout.dim))
+        return ops.layer_norm(node_input, self.affine_weight, self.affine_bias, self.layout, self.eps)
+
+    def __repr__(self):
+        return "{}({}, eps={})".format(self.__class__.__name__, self.irreps, self.eps)
+
+
+def get_norm_layer(norm_type):
+    if norm_type == "layer":
+        return EquivariantLayerNormV2
+    if norm_type is None:
+        return None
+    if norm_type in ("graph", "instance", "fast_layer"):
+        raise NotImplementedError("norm type {!r} is outside the MI355X hot path (every registered model uses "
+                                  "'layer')".format(norm_type))
+    raise ValueError("Norm type {} not supported.".format(norm_type))
+
+
+class RadialProfile(nn.Module):
+    """Linear -> LayerNorm -> SiLU (x2) -> Linear(no bias) + offset; parameters live in ordinary nn.Linear /
+    nn.LayerNorm containers (so name-based weight-decay rules see the same types), compute is HIP."""
+
+    def __init__(self, ch_list, use_layer_norm=True, use_offset=True):
+        super().__init__()
+        assert use_layer_norm and use_offset
+        mods = []
+        for i in range(1, len(ch_list)):
+            last = i == len(ch_list) - 1
+            mods.append(nn.Linear(ch_list[i - 1], ch_list[i], bias=not last))
+            if last:
+                break
+            mods.append(nn.LayerNorm(ch_list[i]))
+            mods.append(nn.SiLU())
+        self.net = nn.Sequential(*mods)
+        self.offset = nn.Parameter(torch.zeros(ch_list[-1]))
+        bound = 1 / math.sqrt(ch_list[-2])
+        nn.init.uniform_(self.offset, -bound, bound)
+
+    def forward(self, f_in):
+        x = f_in
+        mods = list(self.net)
+        i = 0
+        while i < len(mods):
+            lin = mods[i]
+            if i == len(mods) - 1:
+                return ops.dense_linear(x, lin.weight, self.offset)  # y = x W^T + offset
+            ln = mods[i + 1]
+            x = ops.dense_linear(x, lin.weight, lin.bias)
+            x = ops.ln_silu(x, ln.weight, ln.bias, ln.eps)
+            i += 3
+        return x
+
+
+class GaussianRadialBasisLayer(nn.Module):
+    def __init__(self, num_basis, cutoff):
+        super().__init__()
+        self.num_basis, self.cutoff = num_basis, cutoff + 0.0
+        self.mean = nn.Parameter(torch.zeros(1, num_basis))
+        self.std = nn.Parameter(torch.zeros(1, num_basis))
+        self.weight = nn.Parameter(torch.ones(1, 1))
+        self.bias = nn.Parameter(torch.zeros(1, 1))
+        nn.init.uniform_(self.mean, 0, 1.0)
+        nn.init.uniform_(self.std, 1.0 / num_basis, 1.0)
+
+    def forward(self, dist, node_atom=None, edge_src=None, edge_dst=None):
+        return ops.rbf_gaussian(dist, self.mean, self.std, self.weight, self.bias, self.cutoff)
+
+
+class ExpNormalSmearing(nn.Module):
+    """[ref: nets/graph_attention_transformer_md17.py:85-124], non-trainable buffers `means`, `betas`."""
+
+    def __init__(self, cutoff_lower=0.0, cutoff_upper=5.0, num_rbf=50, trainable=False):
+        super().__init__()
+        assert cutoff_lower == 0.0 and not trainable
+        self.cutoff_lower, self.cutoff_upper, self.num_rbf = cutoff_lower, cutoff_upper, num_rbf
+        self.alpha = 5.0 / (cutoff_upper - cutoff_lower)
+        start = torch.exp(torch.scalar_tensor(-cutoff_upper + cutoff_lower))
+        self.register_buffer("means", torch.linspace(start, 1, num_rbf))
+        self.register_buffer("betas", torch.tensor([(2 / num_rbf * (1 - start)) ** -2] * num_rbf))
+
+    def forward(self, dist):
+        return ops.rbf_expnorm(dist, self.means, self.betas, self.alpha, self.cutoff_upper)
+
+
+# ------------------------------------------------------------------------------------------------- edge context
+class EdgeContext:
+    """Per-forward geometry shared by every block: the dst-sorted graph, spherical harmonics, radial basis and
+    the DTP coupling matrices (one tensor per distinct path table, computed once per forward)."""
+
+    def __init__(self, graph, edge_sh, edge_scalars):
+        self.graph, self.edge_sh, self.edge_scalars = graph, edge_sh, edge_scalars
+        self._coupling = {}
+
+    def coupling(self, table):
+        c = self._coupling.get(table.key)
+        if c is None:
+            c = ops.dtp_coupling(self.edge_sh, table)
+            self._coupling[table.key] = c
+        return c
+
+
+class DepthwiseTensorProductModule(nn.Module):
+    """Holds the path table (+ internal weights when shared); `tp` keeps the reference's key `dtp.tp.weight`."""
+
+    def __init__(self, irreps_node_input, irreps_edge_attr, irreps_node_output, internal_weights=False, bias=True):
+        super().__init__()
+        assert not bias
+        self.table = DtpTable(irreps_node_input, irreps_edge_attr, irreps_node_output)
+        self.irreps_out = self.table.irreps_out_unsimplified
+        self.tp = _TensorProductWeights(self.table.weight_numel, internal_weights)
+        # 'uvu' with mul2 == 1: fan_in = 1 -> rescale factor 1 (tensor_product_rescale.py:46,93-110)
+        self.slices_sqrt_k = {}
+
+
+def DepthwiseTensorProduct(irreps_node_input, irreps_edge_attr, irreps_node_output, internal_weights=False, bias=True):
+    return DepthwiseTensorProductModule(irreps_node_input, irreps_edge_attr, irreps_node_output,
+                                        internal_weights=internal_weights, bias=bias)
+
+
+class SeparableFCTP(nn.Module):
+    def __init__(self, irreps_node_input, irreps_edge_attr, irreps_node_output, fc_neurons, use_activation=False,
+                 norm_layer=None, internal_weights=False):
+        super().__init__()
+        assert norm_layer is None
+        self.irreps_node_input = Irreps(irreps_node_input)
+        self.irreps_edge_attr = Irreps(irreps_edge_attr)
+        self.irreps_node_output = Irreps(irreps_node_output)
+        self.dtp = DepthwiseTensorProduct(self.irreps_node_input, self.irreps_edge_attr, self.irreps_node_output,
+                                          bias=False, internal_weights=internal_weights)
+        self.dtp_rad = None
+        if fc_neurons is not None:
+            self.dtp_rad = RadialProfile(fc_neurons + [self.dtp.tp.weight_numel])
+        irreps_lin_output = self.irreps_node_output
+        if use_activation:
+            s, g, gd = irreps2gate(self.irreps_node_output)
+            irreps_lin_output = (s + g + gd).simplify()
+        self.lin = LinearRS(self.dtp.table.irreps_out, irreps_lin_output)
+        self.norm = None
+        self.gate = make_gate(self.irreps_node_output) if use_activation else None
+        self.fused_spec = ops.DtpLinearSpec(self.dtp.table, self.lin.layout_out) if self.dtp.table.fusable else None
+        if internal_weights:
+            # row (path, channel) of the stacked lin weight -> index of its shared DTP weight
+            idx = []
+            t = self.dtp.table
+            for l3 in sorted({p["l3"] for p in t.paths}):
+                for p in t.paths:
+                    if p["l3"] == l3:
+                        idx.extend(range(p["w_off"], p["w_off"] + p["mul"]))
+            self.register_buffer("_row_to_w", torch.tensor(idx, dtype=torch.long), persistent=False)
+
+    def folded_lin_weight(self):
+        """lin weight with the shared depth-wise weights folded into its rows:
+        Linear(DTP_w(x)) == Linear'(DTP_1(x)) with W'[(p,u), :] = w[p,u] * W[(p,u), :]."""
+        scale = self.dtp.tp.weight[self._row_to_w]
+        chunks, r = [], 0
+        for (l, _, K, _, N, w_off) in self.lin.spec.pairs:
+            W = self.lin.tp.weight[w_off:w_off + K * N].view(K, N)
+            chunks.append((W * scale[r:r + K, None]).reshape(-1))
+            r += K
+        return torch.cat(chunks)
+
+    def forward(self, node_input, ectx, use_fused=True):
+        table = self.dtp.table
+        M = ectx.coupling(table)
+        internal = self.dtp.tp.internal_weights
+        w = self.dtp_rad(ectx.edge_scalars) if self.dtp_rad is not None else None
+        bias = self.lin._bias()
+        if use_fused and self.fused_spec is not None:
+            weight = self.folded_lin_weight() if internal else self.lin.tp.weight
+            out = ops.dtp_linear(node_input, M, w, weight, bias, self.fused_spec)
+        else:
+            if internal:
+                w = self.dtp.tp.weight.unsqueeze(0).expand(node_input.shape[0], -1).contiguous()
+            out = self.lin(ops.dtp(node_input, M, w, table))
+        if self.gate is not None:
+            out = self.gate(out)
+        return out
+
+
+class GraphAttention(nn.Module):
+    def __init__(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_output, fc_neurons,
+                 irreps_head, num_heads, irreps_pre_attn=None, rescale_degree=False, nonlinear_message=False,
+                 alpha_drop=0.1, proj_drop=0.1):
+        super().__init__()
+        self.irreps_node_input = Irreps(irreps_node_input)
+        self.irreps_node_attr = Irreps(irreps_node_attr)
+        self.irreps_edge_attr = Irreps(irreps_edge_attr)
+        self.irreps_node_output = Irreps(irreps_node_output)
+        self.irreps_pre_attn = self.irreps_node_input if irreps_pre_attn is None else Irreps(irreps_pre_attn)
+        self.irreps_head = Irreps(irreps_head)
+        self.num_heads = num_heads
+        self.rescale_degree = rescale_degree
+        self.nonlinear_message = nonlinear_message
+        if not nonlinear_message:
+            raise NotImplementedError("the MI355X hot path implements the non-linear message variant "
+                                      "(every BASELINE config); linear-message models are a follow-up")
+        if rescale_degree:
+            raise NotImplementedError("rescale_degree=True is not used by any registered model")
+        if proj_drop != 0.0:
+            raise NotImplementedError("proj_drop != 0 is not used by any registered model")
+
+        self.merge_src = LinearRS(self.irreps_node_input, self.irreps_pre_attn, bias=True)
+        self.merge_dst = LinearRS(self.irreps_node_input, self.irreps_pre_attn, bias=False)
+
+        irreps_attn_heads = _simplified_sorted(self.irreps_head * num_heads)
+        mul_alpha = sum(m for m, ir in irreps_attn_heads if ir.l == 0 and ir.p == 1)
+        self.mul_alpha_head = mul_alpha // num_heads
+        irreps_alpha = Irreps("{}x0e".format(mul_alpha))
+
+        self.sep_act = SeparableFCTP(self.irreps_pre_attn, self.irreps_edge_attr, self.irreps_pre_attn, fc_neurons,
+                                     use_activation=True, norm_layer=None, internal_weights=False)
+        self.sep_alpha = LinearRS(self.sep_act.dtp.table.irreps_out, irreps_alpha)
+        self.sep_value = SeparableFCTP(self.irreps_pre_attn, self.irreps_edge_attr, irreps_attn_heads, fc_neurons=None,
+                                       use_activation=False, norm_layer=None, internal_weights=True)
+        self.alpha_fused_spec = (ops.DtpLinearSpec(self.sep_act.dtp.table, self.sep_alpha.layout_out)
+                                 if self.sep_act.dtp.table.fusable else None)
+        self.heads_layout = RowLayout(irreps_attn_heads)
+
+        self.alpha_dot = nn.Parameter(torch.randn(1, num_heads, self.mul_alpha_head))
+        stdv = math.sqrt(6.0 / (self.alpha_dot.size(-2) + self.alpha_dot.size(-1)))  # torch_geometric glorot
+        self.alpha_dot.data.uniform_(-stdv, stdv)
+        self.alpha_drop = float(alpha_drop)
+        self.alpha_dropout = nn.Dropout(alpha_drop) if alpha_drop != 0.0 else None  # marker module (no params)
+        self.proj = LinearRS(irreps_attn_heads, self.irreps_node_output)
+        self.proj_drop = None
+        self.use_fused = True
+
+    def forward(self, node_input, node_attr=None, edge_src=None, edge_dst=None, edge_attr=None, edge_scalars=None,
+                batch=None, ectx=None, **kwargs):
+        g = ectx.graph
+        message = ops.gather_add(self.merge_src(node_input), self.merge_dst(node_input), g)
+        sa = self.sep_act
+        table = sa.dtp.table
+        M = ectx.coupling(table)
+        weight = sa.dtp_rad(ectx.edge_scalars)
+        if self.use_fused and sa.fused_spec is not None:
+            value = ops.dtp_linear(message, M, weight, sa.lin.tp.weight, sa.lin._bias(), sa.fused_spec)
+            alpha = ops.dtp_linear(message, M, weight, self.sep_alpha.tp.weight, self.sep_alpha._bias(),
+                                   self.alpha_fused_spec)
+        else:
+            mid = ops.dtp(message, M, weight, table)
+            alpha = self.sep_alpha(mid)
+            value = sa.lin(mid)
+        value = sa.gate(value)
+        value = self.sep_value(value, ectx, use_fused=self.use_fused)
+        logit = ops.alpha_logits(alpha, self.alpha_dot, self.num_heads, self.mul_alpha_head,
+                                 so3.C_SMOOTH_LEAKY_RELU_02)
+        drop_p, seed = 0.0, 0
+        if self.training and self.alpha_drop > 0.0:
+            drop_p = self.alpha_drop
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+        attn = ops.attn_aggregate(logit, value, g, self.num_heads, self.heads_layout, drop_p, seed)
+        return self.proj(attn)
+
+
+class FeedForwardNetwork(nn.Module):
+    def __init__(self, irreps_node_input, irreps_node_attr, irreps_node_output, irreps_mlp_mid=None, proj_drop=0.1):
+        super().__init__()
+        if proj_drop != 0.0:
+            raise NotImplementedError("proj_drop != 0 is not used by any registered model")
+        self.irreps_node_input = Irreps(irreps_node_input)
+        self.irreps_node_attr = Irreps(irreps_node_attr)
+        self.irreps_mlp_mid = Irreps(irreps_mlp_mid) if irreps_mlp_mid is not None else self.irreps_node_input
+        self.irreps_node_output = Irreps(irreps_node_output)
+        self.fctp_1 = FullyConnectedTensorProductRescaleSwishGate(self.irreps_node_input, self.irreps_node_attr,
+                                                                  self.irreps_mlp_mid, bias=True, rescale=_RESCALE)
+        self.fctp_2 = FullyConnectedTensorProductRescale(self.irreps_mlp_mid, self.irreps_node_attr,
+                                                         self.irreps_node_output, bias=True, rescale=_RESCALE)
+        self.proj_drop = None
+
+    def forward(self, node_input, node_attr=None, **kwargs):
+        return self.fctp_2(self.fctp_1(node_input, node_attr), node_attr)
+
+
+class TransBlock(nn.Module):
+    def __init__(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_output, fc_neurons,
+                 irreps_head, num_heads, irreps_pre_attn=None, rescale_degree=False, nonlinear_message=False,
+                 alpha_drop=0.1, proj_drop=0.1, drop_path_rate=0.0, irreps_mlp_mid=None, norm_layer="layer"):
+        super().__init__()
+        if drop_path_rate != 0.0:
+            raise NotImplementedError("drop_path_rate != 0 is not used by any registered model")
+        self.irreps_node_input = Irreps(irreps_node_input)
+        self.irreps_node_attr = Irreps(irreps_node_attr)
+        self.irreps_edge_attr = Irreps(irreps_edge_attr)
+        self.irreps_node_output = Irreps(irreps_node_output)
+        self.irreps_mlp_mid = Irreps(irreps_mlp_mid) if irreps_mlp_mid is not None else self.irreps_node_input
+        norm = get_norm_layer(norm_layer)
+        self.norm_1 = norm(self.irreps_node_input)
+        self.ga = GraphAttention(self.irreps_node_input, self.irreps_node_attr, self.irreps_edge_attr,
+                                 self.irreps_node_input, fc_neurons, irreps_head, num_heads, irreps_pre_attn,
+                                 rescale_degree, nonlinear_message, alpha_drop, proj_drop)
+        self.drop_path = None
+        self.norm_2 = norm(self.irreps_node_input)
+        self.ffn = FeedForwardNetwork(self.irreps_node_input, self.irreps_node_attr, self.irreps_node_output,
+                                      self.irreps_mlp_mid, proj_drop)
+        self.ffn_shortcut = None
+        if self.irreps_node_input != self.irreps_node_output:
+            self.ffn_shortcut = FullyConnectedTensorProductRescale(self.irreps_node_input, self.irreps_node_attr,
+                                                                   self.irreps_node_output, bias=True,
+                                                                   rescale=_RESCALE)
+
+    def forward(self, node_input, node_attr=None, ectx=None, **kwargs):
+        node_output = node_input + self.ga(self.norm_1(node_input), ectx=ectx)
+        node_features = self.ffn(self.norm_2(node_output), node_attr)
+        if self.ffn_shortcut is not None:
+            node_output = self.ffn_shortcut(node_output, node_attr)
+        return node_output + node_features
+
+
+class NodeEmbeddingNetwork(nn.Module):
+    def __init__(self, irreps_node_embedding, max_atom_type, bias=True):
+        super().__init__()
+        self.max_atom_type = max_atom_type
+        self.irreps_node_embedding = Irreps(irreps_node_embedding)
+        self.atom_type_lin = LinearRS(Irreps("{}x0e".format(max_atom_type)), self.irreps_node_embedding, bias=bias)
+        self.atom_type_lin.tp.weight.data.mul_(max_atom_type ** 0.5)
+        self.D = self.atom_type_lin.layout_out.dim
+        self.C = self.atom_type_lin.layout_out.mul_of(0)
+
+    def forward(self, node_atom):
+        """one_hot(node_atom) @ W + b == row lookup; returns the embedding only (attr/one-hot are unused)."""
+        W = self.atom_type_lin.tp.weight.view(self.max_atom_type, self.C)
+        emb = ops.embed(node_atom.to(torch.int32), W, self.atom_type_lin._bias(), self.D)
+        return emb, None, None
+
+
+class ScaledScatter(nn.Module):
+    def __init__(self, avg_aggregate_num):
+        super().__init__()
+        self.avg_aggregate_num = avg_aggregate_num + 0.0
+
+    def forward(self, x, ptr, seg_of, nseg):
+        return ops.segment_sum(x, ptr, seg_of, nseg, 1.0 / (self.avg_aggregate_num ** 0.5))
+
+    def extra_repr(self):
+        return "avg_aggregate_num={}".format(self.avg_aggregate_num)
+
+
+class EdgeDegreeEmbeddingNetwork(nn.Module):
+    def __init__(self, irreps_node_embedding, irreps_edge_attr, fc_neurons, avg_aggregate_num):
+        super().__init__()
+        irreps_node_embedding = Irreps(irreps_node_embedding)
+        self.exp = LinearRS(Irreps("1x0e"), irreps_node_embedding, bias=_USE_BIAS, rescale=_RESCALE)
+        self.dw = DepthwiseTensorProduct(irreps_node_embedding, irreps_edge_attr, irreps_node_embedding,
+                                         internal_weights=False, bias=False)
+        self.rad = RadialProfile(fc_neurons + [self.dw.tp.weight_numel])
+        self.proj = LinearRS(self.dw.table.irreps_out, irreps_node_embedding)
+        self.scale_scatter = ScaledScatter(avg_aggregate_num)
+        self.fused_spec = ops.DtpLinearSpec(self.dw.table, self.proj.layout_out) if self.dw.table.fusable else None
+        self.D = self.exp.layout_out.dim
+        self.C = self.exp.layout_out.mul_of(0)
+        self.use_fused = True
+
+    def forward(self, node_input, ectx):
+        g = ectx.graph
+        # exp(ones): the same row for every node == lookup of row 0
+        zeros = torch.zeros(g.N, dtype=torch.int32, device=node_input.device)
+        node_features = ops.embed(zeros, self.exp.tp.weight.view(1, self.C), self.exp._bias(), self.D)
+        weight = self.rad(ectx.edge_scalars)
+        src_features = ops.gather_add(node_features, None, g)
+        M = ectx.coupling(self.dw.table)
+        if self.use_fused and self.fused_spec is not None:
+            edge_features = ops.dtp_linear(src_features, M, weight, self.proj.tp.weight, self.proj._bias(),
+                                           self.fused_spec)
+        else:
+            edge_features = self.proj(ops.dtp(src_features, M, weight, self.dw.table))
+        seg_of = g.dst
+        return self.scale_scatter(edge_features, g.row_ptr, seg_of, g.N)

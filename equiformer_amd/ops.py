@@ -1,0 +1,699 @@
+"""Autograd operators of the Equiformer hot path; every forward and backward is one or more launches of
+libequiformer_hip.so through its C ABI (include/equiformer_hip.h).  No operator here has a CPU / eager fallback:
+tensors must live on the GPU, otherwise `HipOnlyError` is raised.
+
+The operators are the closed primitive set of SURVEY.md Appendix B; `equiformer_amd.nets` composes them into the
+reference's module tree.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import lib
+from .lib import EqfRows, call
+
+
+class HipOnlyError(RuntimeError):
+    pass
+
+
+def _p(t, off=0):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr() + 4 * off)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipOnlyError("the Equiformer hot path runs on MI355X only (got a %s tensor); there is no CPU fallback"
+                               % t.device)
+        if t.dtype not in (torch.float32, torch.int32):
+            raise HipOnlyError("kernels take fp32 data / int32 indices, got %s" % t.dtype)
+        if not t.is_contiguous():
+            raise HipOnlyError("non-contiguous tensor handed to a HIP kernel")
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def rows(d, ld, inner):
+    return EqfRows(int(d), int(ld), int(inner))
+
+
+# ------------------------------------------------------------------------------------------------- layer norm
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, layout, eps):
+        x = _c(x)
+        _chk(x, weight, bias)
+        n = x.shape[0]
+        y = torch.empty_like(x)
+        rstd = torch.empty((n, len(layout.segs)), device=x.device, dtype=torch.float32)
+        mean0 = torch.empty((n,), device=x.device, dtype=torch.float32)
+        call("eqf_layernorm_fwd", _p(x), _p(weight), _p(bias), _p(y), _p(rstd), _p(mean0), n, layout.c_ref,
+             float(eps), _stream())
+        ctx.save_for_backward(x, weight, rstd, mean0)
+        ctx.layout = layout
+        ctx.nb = bias.numel()
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight, rstd, mean0 = ctx.saved_tensors
+        dy = _c(dy)
+        _chk(dy)
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(weight)
+        db = torch.zeros(ctx.nb, device=x.device, dtype=torch.float32)
+        call("eqf_layernorm_bwd", _p(x), _p(weight), _p(dy), _p(rstd), _p(mean0), _p(dx), _p(dw), _p(db), x.shape[0],
+             ctx.layout.c_ref, _stream())
+        return dx, dw, db, None, None
+
+
+def layer_norm(x, weight, bias, layout, eps=1e-5):
+    return _LayerNorm.apply(x, weight, bias, layout, eps)
+
+
+# ------------------------------------------------------------------------------------------------- per-degree linear
+class LinearSpec:
+    """Pairs (degree-wise GEMMs) of a LinearRS / FCTP-with-scalar-attr between two row layouts.
+
+    weight offsets follow e3nn's flat `tp.weight`: instructions ordered by input segment, each [mul_in, mul_out].
+    `in_irreps` may be unsimplified (several consecutive segments of the same degree, e.g. the DTP output): the
+    consecutive [mul_i, N] blocks of one degree form one row-major [K, N] matrix."""
+
+    def __init__(self, in_layout, out_layout):
+        self.in_layout, self.out_layout = in_layout, out_layout
+        self.pairs = []  # (l, in_off, K, out_off, N, w_off)
+        w_off = 0
+        for (K, l), in_off in zip(in_layout.segs, in_layout.offsets):
+            j = out_layout.seg_index(l)
+            if j is None:
+                continue
+            N = out_layout.segs[j][0]
+            self.pairs.append((l, in_off, K, out_layout.offsets[j], N, w_off))
+            w_off += K * N
+        self.weight_numel = w_off
+        self.out_covered = len(self.pairs) == len(out_layout.segs)
+        self.in_covered = len(self.pairs) == len(in_layout.segs)
+        self.bias_dim = out_layout.mul_of(0)
+        self.fan_in = {l: K for (l, _, K, _, _, _) in self.pairs}
+
+
+class _IrrepsLinear(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, spec):
+        x = _c(x)
+        weight = _c(weight)
+        _chk(x, weight, bias)
+        n = x.shape[0]
+        Din, Dout = spec.in_layout.dim, spec.out_layout.dim
+        assert x.shape[1] == Din and weight.numel() == spec.weight_numel
+        out = (torch.empty if spec.out_covered else torch.zeros)((n, Dout), device=x.device, dtype=torch.float32)
+        st = _stream()
+        for (l, in_off, K, out_off, N, w_off) in spec.pairs:
+            d = 2 * l + 1
+            b = _p(bias) if (l == 0 and bias is not None) else None
+            call("eqf_gemm_nn", _p(x, in_off), rows(d, Din, K), _p(weight, w_off), N, _p(out, out_off), rows(d, Dout, N),
+                 b, n * d, N, K, 0, st)
+        ctx.save_for_backward(x, weight)
+        ctx.spec = spec
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        spec = ctx.spec
+        dy = _c(dy)
+        _chk(dy)
+        n = x.shape[0]
+        Din, Dout = spec.in_layout.dim, spec.out_layout.dim
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (torch.empty if spec.in_covered else torch.zeros)((n, Din), device=x.device, dtype=torch.float32)
+            for (l, in_off, K, out_off, N, w_off) in spec.pairs:
+                d = 2 * l + 1
+                call("eqf_gemm_nt", _p(dy, out_off), rows(d, Dout, N), _p(weight, w_off), N, _p(dx, in_off),
+                     rows(d, Din, K), None, n * d, K, N, 0, st)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(weight)
+            for (l, in_off, K, out_off, N, w_off) in spec.pairs:
+                d = 2 * l + 1
+                call("eqf_gemm_tn", _p(x, in_off), rows(d, Din, K), _p(dy, out_off), rows(d, Dout, N), _p(dw, w_off), N,
+                     K, N, n * d, st)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(spec.bias_dim, device=x.device, dtype=torch.float32)
+            j = spec.out_layout.seg_index(0)
+            call("eqf_colsum", _p(dy, spec.out_layout.offsets[j]), rows(1, Dout, 0), n, spec.bias_dim, _p(db), st)
+        return dx, dw, db, None
+
+
+def irreps_linear(x, weight, bias, spec):
+    return _IrrepsLinear.apply(x, weight, bias, spec)
+
+
+class _DenseLinear(Function):
+    """torch.nn.Linear semantics (y = x W^T + b) on the exact-fp32 MFMA path."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _c(x)
+        weight = _c(weight)
+        _chk(x, weight, bias)
+        M, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        call("eqf_gemm_nt", _p(x), rows(1, K, 0), _p(weight), K, _p(y), rows(1, N, 0), _p(bias), M, N, K, 0, _stream())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _c(dy)
+        _chk(dy)
+        M, K = x.shape
+        N = weight.shape[0]
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("eqf_gemm_nn", _p(dy), rows(1, N, 0), _p(weight), K, _p(dx), rows(1, K, 0), None, M, K, N, 0, st)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(weight)
+            call("eqf_gemm_tn", _p(dy), rows(1, N, 0), _p(x), rows(1, K, 0), _p(dw), K, N, K, M, st)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(N, device=x.device, dtype=torch.float32)
+            call("eqf_colsum", _p(dy), rows(1, N, 0), M, N, _p(db), st)
+        return dx, dw, db
+
+
+def dense_linear(x, weight, bias=None):
+    return _DenseLinear.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------- activations
+class _Gate(Function):
+    @staticmethod
+    def forward(ctx, x, S, gated_layout, c_silu, c_sig):
+        x = _c(x)
+        _chk(x)
+        n = x.shape[0]
+        G = sum(m for m, _ in gated_layout.segs)
+        Dout = S + gated_layout.dim
+        assert x.shape[1] == S + G + gated_layout.dim
+        y = torch.empty((n, Dout), device=x.device, dtype=torch.float32)
+        call("eqf_gate_fwd", _p(x), _p(y), n, S, gated_layout.c_ref, c_silu, c_sig, _stream())
+        ctx.save_for_backward(x)
+        ctx.args = (S, gated_layout, c_silu, c_sig)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        S, gated_layout, c_silu, c_sig = ctx.args
+        dy = _c(dy)
+        _chk(dy)
+        dx = torch.empty_like(x)
+        call("eqf_gate_bwd", _p(x), _p(dy), _p(dx), x.shape[0], S, gated_layout.c_ref, c_silu, c_sig, _stream())
+        return dx, None, None, None, None
+
+
+def gate(x, S, gated_layout, c_silu, c_sig):
+    return _Gate.apply(x, S, gated_layout, c_silu, c_sig)
+
+
+class _ScaledSilu(Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        x = _c(x)
+        _chk(x)
+        y = torch.empty_like(x)
+        call("eqf_silu_fwd", _p(x), _p(y), x.numel(), c, _stream())
+        ctx.save_for_backward(x)
+        ctx.c = c
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        _chk(dy)
+        dx = torch.empty_like(x)
+        call("eqf_silu_bwd", _p(x), _p(dy), _p(dx), x.numel(), ctx.c, _stream())
+        return dx, None
+
+
+def scaled_silu(x, c):
+    return _ScaledSilu.apply(x, c)
+
+
+class _LnSilu(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        _chk(x, gamma, beta)
+        y = torch.empty_like(x)
+        call("eqf_lnsilu_fwd", _p(x), _p(gamma), _p(beta), _p(y), x.shape[0], x.shape[1], eps, _stream())
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        dy = _c(dy)
+        _chk(dy)
+        dx = torch.empty_like(x)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(beta)
+        call("eqf_lnsilu_bwd", _p(x), _p(gamma), _p(beta), _p(dy), _p(dx), _p(dg), _p(db), x.shape[0], x.shape[1],
+             ctx.eps, _stream())
+        return dx, dg, db, None
+
+
+def ln_silu(x, gamma, beta, eps=1e-5):
+    return _LnSilu.apply(x, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------------------- embedding
+class _Embed(Function):
+    @staticmethod
+    def forward(ctx, types, W, b, D):
+        _chk(types, W, b)
+        n = types.shape[0]
+        C = W.shape[1]
+        y = torch.empty((n, D), device=W.device, dtype=torch.float32)
+        call("eqf_embed_fwd", _p(types), _p(W), _p(b), _p(y), n, C, D, _stream())
+        ctx.save_for_backward(types)
+        ctx.shape = (W.shape, D, b is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (types,) = ctx.saved_tensors
+        wshape, D, has_b = ctx.shape
+        dy = _c(dy)
+        _chk(dy)
+        dW = torch.zeros(wshape, device=dy.device, dtype=torch.float32)
+        db = torch.zeros(wshape[1], device=dy.device, dtype=torch.float32) if has_b else None
+        call("eqf_embed_bwd", _p(types), _p(dy), _p(dW), _p(db), types.shape[0], wshape[1], D, _stream())
+        return None, dW, db, None
+
+
+def embed(types, W, b, D):
+    """W: [num_types, C] (row lookup), b: [C]; output rows [D] with columns >= C zero."""
+    return _Embed.apply(types, _c(W), b, D)
+
+
+# ------------------------------------------------------------------------------------------------- graph ops
+class _GatherAdd(Function):
+    @staticmethod
+    def forward(ctx, a, b, graph):
+        a = _c(a)
+        b = _c(b) if b is not None else None
+        _chk(a, b)
+        D = a.shape[1]
+        msg = torch.empty((graph.E, D), device=a.device, dtype=torch.float32)
+        call("eqf_gather_add_fwd", _p(a), _p(b), _p(graph.src), _p(graph.dst), _p(msg), graph.E, D, _stream())
+        ctx.graph = graph
+        ctx.has_b = b is not None
+        ctx.n = a.shape[0]
+        return msg
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dmsg):
+        g = ctx.graph
+        dmsg = _c(dmsg)
+        _chk(dmsg)
+        D = dmsg.shape[1]
+        st = _stream()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty((ctx.n, D), device=dmsg.device, dtype=torch.float32)
+            call("eqf_segment_sum", _p(dmsg), _p(g.src_ptr), _p(g.src_perm), _p(da), ctx.n, D, 1.0, 0, st)
+        if ctx.has_b and ctx.needs_input_grad[1]:
+            db = torch.empty((ctx.n, D), device=dmsg.device, dtype=torch.float32)
+            call("eqf_segment_sum", _p(dmsg), _p(g.row_ptr), None, _p(db), ctx.n, D, 1.0, 0, st)
+        return da, db, None
+
+
+def gather_add(a, b, graph):
+    """msg[e] = a[src[e]] + b[dst[e]]  (b may be None)."""
+    return _GatherAdd.apply(a, b, graph)
+
+
+class _SegmentSum(Function):
+    @staticmethod
+    def forward(ctx, x, ptr, seg_of, nseg, scale):
+        x = _c(x)
+        _chk(x, ptr, seg_of)
+        D = x.shape[1]
+        out = torch.empty((nseg, D), device=x.device, dtype=torch.float32)
+        call("eqf_segment_sum", _p(x), _p(ptr), None, _p(out), nseg, D, scale, 0, _stream())
+        ctx.save_for_backward(seg_of)
+        ctx.args = (x.shape[0], D, scale)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (seg_of,) = ctx.saved_tensors
+        n, D, scale = ctx.args
+        dout = _c(dout)
+        _chk(dout)
+        dx = torch.empty((n, D), device=dout.device, dtype=torch.float32)
+        call("eqf_segment_bcast", _p(dout), _p(seg_of), _p(dx), n, D, scale, _stream())
+        return dx, None, None, None, None
+
+
+def segment_sum(x, ptr, seg_of, nseg, scale=1.0):
+    """out[s] = scale * sum of the rows of segment s (rows of a segment are contiguous; ptr = CSR offsets)."""
+    return _SegmentSum.apply(x, ptr, seg_of, nseg, float(scale))
+
+
+class _EdgeGeom(Function):
+    @staticmethod
+    def forward(ctx, pos, offsets, graph, lmax):
+        pos = _c(pos)
+        _chk(pos, offsets)
+        E = graph.E
+        vec = torch.empty((E, 3), device=pos.device, dtype=torch.float32)
+        length = torch.empty((E,), device=pos.device, dtype=torch.float32)
+        sh = torch.empty((E, (lmax + 1) ** 2), device=pos.device, dtype=torch.float32)
+        call("eqf_edge_geom_fwd", _p(pos), _p(graph.src), _p(graph.dst), _p(offsets), E, lmax, _p(vec), _p(length),
+             _p(sh), _stream())
+        ctx.save_for_backward(vec)
+        ctx.graph, ctx.lmax, ctx.n = graph, lmax, pos.shape[0]
+        ctx.mark_non_differentiable(vec)
+        return vec, length, sh
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, _dvec, dlen, dsh):
+        (vec,) = ctx.saved_tensors
+        g = ctx.graph
+        dlen = _c(dlen) if dlen is not None else None
+        dsh = _c(dsh) if dsh is not None else None
+        _chk(dlen, dsh)
+        st = _stream()
+        dvec = torch.empty_like(vec)
+        call("eqf_edge_geom_bwd", _p(vec), _p(dsh), _p(dlen), g.E, ctx.lmax, _p(dvec), st)
+        # d pos[n] = sum_{src(e)=n} dvec[e] - sum_{dst(e)=n} dvec[e]   (segmented, no atomics)
+        dpos = torch.empty((ctx.n, 3), device=vec.device, dtype=torch.float32)
+        call("eqf_segment_sum", _p(dvec), _p(g.src_ptr), _p(g.src_perm), _p(dpos), ctx.n, 3, 1.0, 0, st)
+        call("eqf_segment_sum", _p(dvec), _p(g.row_ptr), None, _p(dpos), ctx.n, 3, -1.0, 1, st)
+        return dpos, None, None, None
+
+
+def edge_geometry(pos, offsets, graph, lmax):
+    """(edge_vec [non-differentiable copy], edge_length, edge_sh)."""
+    return _EdgeGeom.apply(pos, offsets, graph, lmax)
+
+
+class _RbfGaussian(Function):
+    @staticmethod
+    def forward(ctx, length, mean, std, weight, bias, cutoff):
+        _chk(length, mean, std, weight, bias)
+        E, R = length.shape[0], mean.numel()
+        out = torch.empty((E, R), device=length.device, dtype=torch.float32)
+        call("eqf_rbf_gaussian_fwd", _p(length), E, R, _p(mean), _p(std), _p(weight), _p(bias), cutoff, _p(out),
+             _stream())
+        ctx.save_for_backward(length, mean, std, weight, bias)
+        ctx.cutoff = cutoff
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        length, mean, std, weight, bias = ctx.saved_tensors
+        dout = _c(dout)
+        _chk(dout)
+        E, R = length.shape[0], mean.numel()
+        dm, ds = torch.zeros_like(mean), torch.zeros_like(std)
+        dw, db = torch.zeros_like(weight), torch.zeros_like(bias)
+        dlen = torch.empty_like(length) if ctx.needs_input_grad[0] else None
+        call("eqf_rbf_gaussian_bwd", _p(length), _p(dout), E, R, _p(mean), _p(std), _p(weight), _p(bias), ctx.cutoff,
+             _p(dm), _p(ds), _p(dw), _p(db), _p(dlen), _stream())
+        return dlen, dm, ds, dw, db, None
+
+
+def rbf_gaussian(length, mean, std, weight, bias, cutoff):
+    return _RbfGaussian.apply(length, mean, std, weight, bias, float(cutoff))
+
+
+class _RbfExpNorm(Function):
+    @staticmethod
+    def forward(ctx, length, means, betas, alpha, cutoff):
+        _chk(length, means, betas)
+        E, R = length.shape[0], means.numel()
+        out = torch.empty((E, R), device=length.device, dtype=torch.float32)
+        call("eqf_rbf_expnorm_fwd", _p(length), E, R, _p(means), _p(betas), alpha, cutoff, _p(out), _stream())
+        ctx.save_for_backward(length, means, betas)
+        ctx.args = (alpha, cutoff)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        length, means, betas = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        dout = _c(dout)
+        _chk(dout)
+        dlen = torch.empty_like(length)
+        call("eqf_rbf_expnorm_bwd", _p(length), _p(dout), length.shape[0], means.numel(), _p(means), _p(betas),
+             ctx.args[0], ctx.args[1], _p(dlen), _stream())
+        return dlen, None, None, None, None
+
+
+def rbf_expnorm(length, means, betas, alpha, cutoff):
+    return _RbfExpNorm.apply(length, means, betas, float(alpha), float(cutoff))
+
+
+# ------------------------------------------------------------------------------------------------- DTP
+class _Coupling(Function):
+    @staticmethod
+    def forward(ctx, sh, table):
+        sh = _c(sh)
+        _chk(sh)
+        E = sh.shape[0]
+        M = torch.empty((E, table.m_numel), device=sh.device, dtype=torch.float32)
+        call("eqf_dtp_coupling_fwd", _p(sh), _p(table.cg(sh.device)), table.c_ref, _p(M), E, _stream())
+        ctx.table, ctx.shape = table, sh.shape
+        return M
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dM):
+        dM = _c(dM)
+        _chk(dM)
+        dsh = torch.empty(ctx.shape, device=dM.device, dtype=torch.float32)
+        call("eqf_dtp_coupling_bwd", _p(dM), _p(ctx.table.cg(dM.device)), ctx.table.c_ref, _p(dsh), ctx.shape[0],
+             _stream())
+        return dsh, None
+
+
+def dtp_coupling(sh, table):
+    return _Coupling.apply(sh, table)
+
+
+class _Dtp(Function):
+    """Un-fused depth-wise tensor product (materialises the [E, out_dim] result)."""
+
+    @staticmethod
+    def forward(ctx, x, coupling, w, table):
+        x, coupling = _c(x), _c(coupling)
+        w = _c(w) if w is not None else None
+        _chk(x, coupling, w)
+        E = x.shape[0]
+        out = torch.empty((E, table.layout_out.dim), device=x.device, dtype=torch.float32)
+        call("eqf_dtp_fwd", _p(x), _p(coupling), _p(w), table.c_ref, _p(out), E, _stream())
+        ctx.save_for_backward(x, coupling, w)
+        ctx.table = table
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, coupling, w = ctx.saved_tensors
+        dout = _c(dout)
+        _chk(dout)
+        E = x.shape[0]
+        dx = torch.zeros_like(x)
+        dw = torch.empty_like(w) if (w is not None and ctx.needs_input_grad[2]) else None
+        dM = torch.empty_like(coupling) if ctx.needs_input_grad[1] else None
+        call("eqf_dtp_bwd", _p(x), _p(coupling), _p(w), ctx.table.c_ref, _p(dout), _p(dx), _p(dw), _p(dM), E, _stream())
+        return dx, dM, dw, None
+
+
+def dtp(x, coupling, w, table):
+    return _Dtp.apply(x, coupling, w, table)
+
+
+class DtpLinearSpec:
+    """DTP output (degree l3, K(l3) channels) -> per-degree linear to `out_layout` (N(l3) channels).
+    Flat weight = [K(l3), N(l3)] blocks in ascending degree (e3nn LinearRS order on the simplified DTP irreps)."""
+
+    def __init__(self, table, out_layout):
+        self.table, self.out_layout = table, out_layout
+        self.blocks = []  # (l3, K, N, w_off, mid_off, out_off)
+        w_off = 0
+        for (K, l3), mid_off in zip(table.layout_out.segs, table.layout_out.offsets):
+            j = out_layout.seg_index(l3)
+            if j is None:
+                continue
+            N = out_layout.segs[j][0]
+            self.blocks.append((l3, K, N, w_off, mid_off, out_layout.offsets[j]))
+            w_off += K * N
+        self.weight_numel = w_off
+        if len(self.blocks) != len(out_layout.segs):
+            raise NotImplementedError("every output degree of a fused DTP-linear must be fed by the DTP")
+        self.bias_dim = out_layout.mul_of(0)
+
+
+class _DtpLinear(Function):
+    """out = Linear(DTP(x, sh, w)) with the DTP result generated inside the GEMM (never stored)."""
+
+    @staticmethod
+    def forward(ctx, x, coupling, w, weight, bias, spec):
+        x, coupling, weight = _c(x), _c(coupling), _c(weight)
+        w = _c(w) if w is not None else None
+        _chk(x, coupling, w, weight, bias)
+        E = x.shape[0]
+        assert weight.numel() == spec.weight_numel
+        out = torch.empty((E, spec.out_layout.dim), device=x.device, dtype=torch.float32)
+        Wl = (ctypes.c_void_p * 8)()
+        for (l3, K, N, w_off, _, _) in spec.blocks:
+            Wl[l3] = weight.data_ptr() + 4 * w_off
+        call("eqf_dtp_linear_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(bias), _p(out),
+             spec.out_layout.c_ref, E, _stream())
+        ctx.save_for_backward(x, coupling, w, weight)
+        ctx.spec = spec
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, coupling, w, weight = ctx.saved_tensors
+        spec = ctx.spec
+        table = spec.table
+        dout = _c(dout)
+        _chk(dout)
+        E = x.shape[0]
+        st = _stream()
+        Dout, Dmid = spec.out_layout.dim, table.layout_out.dim
+        dx = dM = dw = dweight = dbias = None
+        need_mid = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (w is not None and ctx.needs_input_grad[2])
+        if need_mid:
+            covered = len(spec.blocks) == len(table.layout_out.segs)
+            dmid = (torch.empty if covered else torch.zeros)((E, Dmid), device=x.device, dtype=torch.float32)
+            for (l3, K, N, w_off, mid_off, out_off) in spec.blocks:
+                d = 2 * l3 + 1
+                call("eqf_gemm_nt", _p(dout, out_off), rows(d, Dout, N), _p(weight, w_off), N, _p(dmid, mid_off),
+                     rows(d, Dmid, K), None, E * d, K, N, 0, st)
+            dx = torch.zeros_like(x)
+            dw = torch.empty_like(w) if (w is not None and ctx.needs_input_grad[2]) else None
+            dM = torch.empty_like(coupling) if ctx.needs_input_grad[1] else None
+            call("eqf_dtp_bwd", _p(x), _p(coupling), _p(w), table.c_ref, _p(dmid), _p(dx), _p(dw), _p(dM), E, st)
+            del dmid
+        if ctx.needs_input_grad[3]:
+            dweight = torch.zeros_like(weight)
+            dWl = (ctypes.c_void_p * 8)()
+            for (l3, K, N, w_off, _, _) in spec.blocks:
+                dWl[l3] = dweight.data_ptr() + 4 * w_off
+            call("eqf_dtp_linear_wgrad", _p(x), _p(coupling), _p(w), table.c_ref, _p(dout), spec.out_layout.c_ref, dWl,
+                 E, st)
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            dbias = torch.zeros(spec.bias_dim, device=x.device, dtype=torch.float32)
+            j = spec.out_layout.seg_index(0)
+            call("eqf_colsum", _p(dout, spec.out_layout.offsets[j]), rows(1, Dout, 0), E, spec.bias_dim, _p(dbias), st)
+        return dx, dM, dw, dweight, dbias, None
+
+
+def dtp_linear(x, coupling, w, weight, bias, spec):
+    return _DtpLinear.apply(x, coupling, w, weight, bias, spec)
+
+
+# ------------------------------------------------------------------------------------------------- attention
+class _AlphaLogits(Function):
+    @staticmethod
+    def forward(ctx, a, alpha_dot, H, Kh, c):
+        a, alpha_dot = _c(a), _c(alpha_dot)
+        _chk(a, alpha_dot)
+        E = a.shape[0]
+        logit = torch.empty((E, H), device=a.device, dtype=torch.float32)
+        call("eqf_alpha_fwd", _p(a), _p(alpha_dot), _p(logit), E, H, Kh, c, _stream())
+        ctx.save_for_backward(a, alpha_dot)
+        ctx.args = (H, Kh, c)
+        return logit
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dlogit):
+        a, alpha_dot = ctx.saved_tensors
+        H, Kh, c = ctx.args
+        dlogit = _c(dlogit)
+        _chk(dlogit)
+        da = torch.empty_like(a)
+        dd = torch.zeros_like(alpha_dot)
+        call("eqf_alpha_bwd", _p(a), _p(alpha_dot), _p(dlogit), _p(da), _p(dd), a.shape[0], H, Kh, c, _stream())
+        return da, dd, None, None, None
+
+
+def alpha_logits(a, alpha_dot, H, Kh, c):
+    return _AlphaLogits.apply(a, alpha_dot, H, Kh, float(c))
+
+
+class _AttnAggregate(Function):
+    @staticmethod
+    def forward(ctx, logit, value, graph, H, layout, drop_p, seed):
+        logit, value = _c(logit), _c(value)
+        _chk(logit, value)
+        N = graph.N
+        alpha = torch.empty_like(logit)
+        out = torch.empty((N, layout.dim), device=value.device, dtype=torch.float32)
+        call("eqf_attn_aggregate_fwd", _p(logit), _p(value), _p(graph.row_ptr), _p(alpha), _p(out), N, H, layout.c_ref,
+             drop_p, seed, _stream())
+        ctx.save_for_backward(alpha, value)
+        ctx.args = (graph, H, layout, drop_p, seed)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        alpha, value = ctx.saved_tensors
+        graph, H, layout, drop_p, seed = ctx.args
+        dout = _c(dout)
+        _chk(dout)
+        dvalue = torch.empty_like(value)
+        dlogit = torch.empty_like(alpha)
+        call("eqf_attn_aggregate_bwd", _p(alpha), _p(value), _p(graph.row_ptr), _p(dout), _p(dvalue), _p(dlogit),
+             graph.N, H, layout.c_ref, drop_p, seed, _stream())
+        return dlogit, dvalue, None, None, None, None, None
+
+
+def attn_aggregate(logit, value, graph, H, layout, drop_p=0.0, seed=0):
+    return _AttnAggregate.apply(logit, value, graph, H, layout, float(drop_p), int(seed))

@@ -1,0 +1,265 @@
+/*
+ * equiformer_hip.h -- C ABI of libequiformer_hip.so: the MI355X (gfx950) hot path of Equiformer
+ * (atomicarchitects/equiformer), forward and backward.
+ *
+ * The reference has no native boundary of its own: its hot path is Python that dispatches into
+ * e3nn / torch_scatter / torch_cluster / PyG kernels.  Each entry point below replaces one such
+ * dispatch; the reference call site it stands in for is cited as  [ref: file:line]  (paths relative
+ * to the reference repository root).  The Python host package `equiformer_amd.nets` (same registry,
+ * module tree and parameter names as the reference's `nets`) binds these symbols with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers (hipMalloc'ed / torch CUDA tensors' data_ptr()) unless marked
+ *    "host".  fp32 data, int32 indices.  Nothing here allocates, synchronises or touches the host
+ *    copy of any buffer; every launch goes to `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream).  All entry points are safe under HIP-graph capture.
+ *  - Return value: 0 on success, otherwise the hipError_t of the failed launch (as int), or a
+ *    negative EQF_E_* code for argument errors.  Nothing is written on argument errors.
+ *  - Feature tensors are row-major [rows, D].  Inside a row the channels of an irreps list
+ *    mul_0 x l_0 + mul_1 x l_1 + ... are stored segment after segment, and inside the segment of
+ *    degree l as [2l+1][mul]  (component m slow, channel u fast).  This "channel-fastest" (CF)
+ *    layout is the library's internal layout (e3nn uses [mul][2l+1]); for 0e-only tensors the two
+ *    coincide.  `eqf_irreps` describes such a row.
+ *  - Edges are sorted by destination node: `row_ptr[N+1]` (CSR over dst) and `src[E]`, `dst[E]`.
+ */
+#ifndef EQUIFORMER_HIP_H
+#define EQUIFORMER_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EQF_MAX_SEG 8
+#define EQF_MAX_PATHS 64
+
+#define EQF_E_BADARG (-1)
+#define EQF_E_UNSUPPORTED (-2)
+
+/* One row of a feature tensor: nseg segments, segment s has degree l[s] and multiplicity mul[s]. */
+typedef struct eqf_irreps {
+  int nseg;
+  int l[EQF_MAX_SEG];
+  int mul[EQF_MAX_SEG];
+} eqf_irreps;
+
+/* Depth-wise tensor product ('uvu', mul2 == 1) path table.  Path p couples input segment of degree
+ * l1[p] (row offset in_off[p], multiplicity mul[p]) with the spherical harmonic of degree l2[p] into
+ * output degree l3[p]; its mul[p] output channels start at channel out_ch[p] of the output segment
+ * (row offset out_off[p], total channels out_k[p]); its per-edge weights start at w_off[p].
+ * cg_off[p] indexes the dense table  cg[cg_off + (i*(2*l2+1) + j)*(2*l3+1) + k]  which already
+ * includes the sqrt(2*l3+1) path normalisation.                     [ref: e3nn o3.TensorProduct codegen] */
+typedef struct eqf_dtp_paths {
+  int npaths;
+  int sh_dim;      /* (lmax_sh+1)^2: row length of the spherical-harmonics tensor */
+  int in_dim;      /* D of the input rows */
+  int out_dim;     /* D of the output rows */
+  int w_numel;     /* weights per edge */
+  int m_numel;     /* sum_p (2*l1+1)*(2*l3+1): size of the per-edge coupling matrices */
+  int l1[EQF_MAX_PATHS], l2[EQF_MAX_PATHS], l3[EQF_MAX_PATHS], mul[EQF_MAX_PATHS];
+  int in_off[EQF_MAX_PATHS], out_off[EQF_MAX_PATHS], out_ch[EQF_MAX_PATHS], out_k[EQF_MAX_PATHS];
+  int w_off[EQF_MAX_PATHS], cg_off[EQF_MAX_PATHS], m_off[EQF_MAX_PATHS];
+} eqf_dtp_paths;
+
+/* Library identification: returns a static string "equiformer_hip <version> gfx950". */
+const char* eqf_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph construction and edge geometry
+ * ------------------------------------------------------------------------------------------- */
+
+/* Degree of every node in a radius graph: deg[i] = min(max_nbr, #{j != i in the same molecule :
+ * |pos_j - pos_i| < r}).  mol_ptr[n_mol+1] are node offsets of the molecules (nodes of a molecule
+ * are contiguous, as in a PyG Batch).
+ * [ref: torch_cluster.radius_graph call, nets/graph_attention_transformer.py:866-867] */
+int eqf_radius_graph_count(const float* pos, const int* mol_ptr, int n_mol, float r, int max_nbr,
+                           int* deg, void* stream);
+
+/* Fill the dst-sorted edge list given row_ptr = exclusive scan of deg: for node i, sources in
+ * ascending index order (the order torch_cluster emits).  src/dst are [E].                       */
+int eqf_radius_graph_fill(const float* pos, const int* mol_ptr, int n_mol, float r, int max_nbr,
+                          const int* row_ptr, int* src, int* dst, void* stream);
+
+/* edge_vec = pos[src] - pos[dst] (+ offsets, may be NULL), len = |edge_vec|,
+ * sh = Y^0..Y^lmax(edge_vec/len) * sqrt(2l+1)  ("component" normalisation), lmax <= 3.
+ * [ref: nets/graph_attention_transformer.py:868-870,874;  e3nn o3.spherical_harmonics] */
+int eqf_edge_geom_fwd(const float* pos, const int* src, const int* dst, const float* offsets, int E,
+                      int lmax, float* vec, float* len, float* sh, void* stream);
+
+/* d_vec[E,3] from d_sh[E,(lmax+1)^2] (may be NULL) and d_len[E] (may be NULL). */
+int eqf_edge_geom_bwd(const float* vec, const float* d_sh, const float* d_len, int E, int lmax,
+                      float* d_vec, void* stream);
+
+/* Graphormer Gaussian radial basis, out[e,r] = exp(-.5 ((w*len/cutoff+b-mean_r)/std_r)^2)/(sqrt(2*3.14159) std_r),
+ * std_r = |std_r| + 1e-5.                                  [ref: nets/gaussian_rbf.py:5-9,32-40] */
+int eqf_rbf_gaussian_fwd(const float* len, int E, int R, const float* mean, const float* std,
+                         const float* weight, const float* bias, float cutoff, float* out, void* stream);
+/* d_mean[R], d_std[R], d_weight[1], d_bias[1] are ACCUMULATED (+=); d_len[E] (may be NULL) is written. */
+int eqf_rbf_gaussian_bwd(const float* len, const float* d_out, int E, int R, const float* mean,
+                         const float* std, const float* weight, const float* bias, float cutoff,
+                         float* d_mean, float* d_std, float* d_weight, float* d_bias, float* d_len,
+                         void* stream);
+
+/* Exp-normal smearing with cosine cutoff, out[e,r] = .5(cos(pi len/rc)+1)[len<rc] exp(-beta_r (exp(-alpha len)-mu_r)^2).
+ * [ref: nets/graph_attention_transformer_md17.py:51-81,119-124] */
+int eqf_rbf_expnorm_fwd(const float* len, int E, int R, const float* means, const float* betas,
+                        float alpha, float cutoff, float* out, void* stream);
+int eqf_rbf_expnorm_bwd(const float* len, const float* d_out, int E, int R, const float* means,
+                        const float* betas, float alpha, float cutoff, float* d_len, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense contractions on the matrix cores (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32)
+ * ------------------------------------------------------------------------------------------- */
+
+/* "Two-level" row addressing used for the l-segments of CF rows: logical row i of a matrix lives at
+ *    base + (i / d) * ld + (i % d) * inner ,   its elements are contiguous from there.
+ * A plain row-major matrix is d = 1, inner = 0, ld = leading dimension.                          */
+typedef struct eqf_rows {
+  int d;
+  int ld;
+  int inner;
+} eqf_rows;
+
+/* C[i,n] (=|+=) sum_k A[i,k] * B[k,n]  (+ bias[n]).   A: M rows (two-level) x K, B: plain [K,N]
+ * with leading dimension ldb, C: M rows (two-level) x N.  accumulate != 0 adds into C.
+ * [ref: LinearRS / FullyConnectedTensorProductRescale forward, nets/tensor_product_rescale.py:125-136,171-174;
+ *       torch.nn.Linear inside RadialProfile, nets/radial_func.py:46-49] */
+int eqf_gemm_nn(const float* A, eqf_rows ra, const float* B, int ldb, float* C, eqf_rows rc,
+                const float* bias, int M, int N, int K, int accumulate, void* stream);
+/* C[i,n] (=|+=) sum_k A[i,k] * B[n,k] (+ bias[n]).   B: plain [N,K] with leading dimension ldb. */
+int eqf_gemm_nt(const float* A, eqf_rows ra, const float* B, int ldb, float* C, eqf_rows rc,
+                const float* bias, int M, int N, int K, int accumulate, void* stream);
+/* C[m,n] += sum_i A[i,m] * B[i,n]   over R rows (two-level on both operands); C plain [M,N] with
+ * leading dimension ldc.  C is always ACCUMULATED into (split over row chunks with fp32 atomics). */
+int eqf_gemm_tn(const float* A, eqf_rows ra, const float* B, eqf_rows rb, float* C, int ldc, int M,
+                int N, int R, void* stream);
+
+/* out[n] += sum_rows x[row, n]  over a two-level-row matrix (bias gradients). */
+int eqf_colsum(const float* X, eqf_rows rx, int R, int N, float* out, void* stream);
+
+/* Per-edge coupling matrices of a DTP path table (depend on geometry only, shared by every DTP that uses
+ * the same path table -- all blocks of a model):
+ *   coupling[e, m_off[p] + i*(2*l3+1) + k] = sum_j cg_p[i,j,k] * sh[e, l2^2 + j]
+ * so that  DTP(x, sh, w)[e, p, k, u] = w[e,p,u] * sum_i coupling[e,p,i,k] * x[e, l1, i, u].
+ * [ref: o3.TensorProduct('uvu') einsum 'zuv,ijk,zuvij->zuk', nets/tensor_product_rescale.py:33-37] */
+int eqf_dtp_coupling_fwd(const float* sh, const float* cg, const eqf_dtp_paths* paths, float* coupling,
+                         int E, void* stream);
+/* d_sh[E, sh_dim] written from d_coupling[E, m_numel]. */
+int eqf_dtp_coupling_bwd(const float* d_coupling, const float* cg, const eqf_dtp_paths* paths,
+                         float* d_sh, int E, void* stream);
+
+/* Fused depth-wise tensor product -> per-degree linear:  the A operand of the GEMM is generated on the
+ * fly from (x, coupling, w) by the DTP path table and never written to memory.
+ *   out[e, seg(l3)] = DTP(x, sh, w)[e, seg(l3)] . Wl[l3]    (+ bias0 on l3 = 0)
+ * for every output degree present in `paths`.  w may be NULL (all path weights 1).
+ * Wl[l3] are plain [out_k(l3), N(l3)] row-major matrices given as device pointers in a HOST array
+ * indexed by l3 (entries for absent degrees ignored); out_irreps describes the output rows (one
+ * segment per degree).  Requires every path multiplicity to be a multiple of 32.
+ * [ref: SeparableFCTP.forward, nets/graph_attention_transformer.py:234-248] */
+int eqf_dtp_linear_fwd(const float* x, const float* coupling, const float* w,
+                       const eqf_dtp_paths* paths, const float* const* Wl, const float* bias0,
+                       float* out, const eqf_irreps* out_irreps, int E, void* stream);
+/* dWl[l3][k, n] += sum_{e,m} DTP(x,sh,w)[e,l3,m,k] * d_out[e,l3,m,n]  (A operand regenerated). */
+int eqf_dtp_linear_wgrad(const float* x, const float* coupling, const float* w,
+                         const eqf_dtp_paths* paths, const float* d_out,
+                         const eqf_irreps* out_irreps, float* const* dWl, int E, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row-local feature ops (nodes or edges)
+ * ------------------------------------------------------------------------------------------- */
+
+/* EquivariantLayerNormV2 ('component' normalisation, affine).  rstd is [rows, nseg], mean0 is [rows]
+ * (mean of the first 0e segment); both are outputs of fwd and inputs of bwd.
+ * [ref: nets/layer_norm.py:89-152] */
+int eqf_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd,
+                      float* mean0, int rows, const eqf_irreps* irreps, float eps, void* stream);
+/* dx written; d_weight[num_irreps], d_bias[mul of 0e] ACCUMULATED. */
+int eqf_layernorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd,
+                      const float* mean0, float* dx, float* d_weight, float* d_bias, int rows,
+                      const eqf_irreps* irreps, void* stream);
+
+/* Gate: in = [scalars(S) | gates(G) | gated segments], out = [c_silu*silu(scalars) | gated * c_sig*sigmoid(gates)].
+ * `gated` lists the l>0 segments (sum of mul = G).  in rows have S+G+dim(gated) floats, out rows S+dim(gated).
+ * [ref: nets/fast_activation.py:132-148] */
+int eqf_gate_fwd(const float* in, float* out, int rows, int S, const eqf_irreps* gated, float c_silu,
+                 float c_sig, void* stream);
+int eqf_gate_bwd(const float* in, const float* d_out, float* d_in, int rows, int S,
+                 const eqf_irreps* gated, float c_silu, float c_sig, void* stream);
+
+/* y = c * silu(x) elementwise over n floats, and its backward.  [ref: nets/fast_activation.py:68-71] */
+int eqf_silu_fwd(const float* x, float* y, long n, float c, void* stream);
+int eqf_silu_bwd(const float* x, const float* dy, float* dx, long n, float c, void* stream);
+
+/* Radial-MLP inner step: y = silu(LayerNorm_C(x) * gamma + beta), rows of C <= 64 channels (C == 64 in
+ * every reference config).  [ref: nets/radial_func.py:13-36 (nn.LayerNorm + nn.SiLU)] */
+int eqf_lnsilu_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int C,
+                   float eps, void* stream);
+/* dx written; d_gamma[C], d_beta[C] ACCUMULATED. */
+int eqf_lnsilu_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
+                   float* d_gamma, float* d_beta, int rows, int C, float eps, void* stream);
+
+/* Atom-type embedding: y[n, 0:C] = W[type[n], 0:C] + b[0:C], remaining D-C floats of the row zeroed
+ * (LinearRS applied to a one-hot vector).  [ref: nets/graph_attention_transformer.py:682-690] */
+int eqf_embed_fwd(const int* type, const float* W, const float* b, float* y, int rows, int C, int D,
+                  void* stream);
+/* dW[type[n], :] += dy[n, 0:C]; db += dy[n, 0:C]  (ACCUMULATED). */
+int eqf_embed_bwd(const int* type, const float* dy, float* dW, float* db, int rows, int C, int D,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Edge-wise gather / scatter over the dst-sorted radius graph
+ * ------------------------------------------------------------------------------------------- */
+
+/* msg[e,:] = a[src[e],:] + b[dst[e],:]   (b may be NULL).
+ * [ref: nets/graph_attention_transformer.py:487, :729] */
+int eqf_gather_add_fwd(const float* a, const float* b, const int* src, const int* dst, float* msg,
+                       int E, int D, void* stream);
+
+/* out[n,:] (=|+=) scale * sum_{q in [ptr[n], ptr[n+1])} x[perm ? perm[q] : q, :]
+ * Segmented reduction without atomics: the backward of the gather above (ptr/perm = CSR over dst or
+ * over src), ScaledScatter over edges or over the nodes of a molecule.
+ * [ref: torch_scatter.scatter call sites, nets/graph_attention_transformer.py:513,700] */
+int eqf_segment_sum(const float* x, const int* ptr, const int* perm, float* out, int nseg, int D,
+                    float scale, int accumulate, void* stream);
+/* out[q,:] = scale * x[seg_of[q],:]  (row broadcast: backward of eqf_segment_sum with perm == NULL). */
+int eqf_segment_bcast(const float* x, const int* seg_of, float* out, int rows, int D, float scale,
+                      void* stream);
+
+/* Depth-wise tensor product, un-fused form (kept as the building block for shapes the fused GEMM
+ * does not cover and as its on-device cross-check): out[e, :] per eqf_dtp_paths.  w may be NULL.
+ * [ref: DepthwiseTensorProduct + o3.TensorProduct('uvu'), nets/graph_attention_transformer.py:157-183] */
+int eqf_dtp_fwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                float* out, int E, void* stream);
+/* dx[E,in_dim] written; dw[E,w_numel] written if non-NULL (w == NULL means unit weights);
+ * d_coupling[E,m_numel] written if non-NULL (needed only when forces are differentiated). */
+int eqf_dtp_bwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                const float* d_out, float* dx, float* dw, float* d_coupling, int E, void* stream);
+
+/* Attention logits: logit[e,h] = sum_k c * SmoothLeakyReLU_0.2(a[e, h*Kh+k]) * alpha_dot[h,k].
+ * [ref: nets/graph_attention_transformer.py:54-63,506-507] */
+int eqf_alpha_fwd(const float* a, const float* alpha_dot, float* logit, int E, int H, int Kh, float c,
+                  void* stream);
+/* da written; d_alpha_dot[H*Kh] ACCUMULATED. */
+int eqf_alpha_bwd(const float* a, const float* alpha_dot, const float* d_logit, float* da,
+                  float* d_alpha_dot, int E, int H, int Kh, float c, void* stream);
+
+/* Per-destination softmax + weighted aggregation (no atomics, deterministic):
+ *   alpha[e,h] = exp(logit[e,h]-max_seg)/(sum_seg + 1e-16);   keep[e,h] = dropout mask/(1-p) (p = 0: 1)
+ *   out[n, c]  = sum_{e in seg(n)} alpha[e,head(c)] * keep[e,head(c)] * value[e,c]
+ * value/out rows follow `irreps` (the H-head irreps: channel u of a segment belongs to head u / (mul/H)).
+ * alpha[E,H] (post-softmax, pre-dropout) is an output saved for the backward.  drop_p in [0,1);
+ * the mask is a counter-based hash of (seed, e*H+h), recomputed identically in the backward.
+ * [ref: torch_geometric.utils.softmax + Dropout + scatter, nets/graph_attention_transformer.py:508-514] */
+int eqf_attn_aggregate_fwd(const float* logit, const float* value, const int* row_ptr, float* alpha,
+                           float* out, int N, int H, const eqf_irreps* irreps, float drop_p,
+                           unsigned long long seed, void* stream);
+/* d_value[E,D], d_logit[E,H] written. */
+int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* row_ptr,
+                           const float* d_out, float* d_value, float* d_logit, int N, int H,
+                           const eqf_irreps* irreps, float drop_p, unsigned long long seed,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQUIFORMER_HIP_H */
