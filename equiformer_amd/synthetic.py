@@ -35,7 +35,7 @@ _ASPIRIN_POS = np.array([
     [0.03, 0.02, 0.0], [-1.25, 0.77, 0.1], [-1.10, -3.35, 0.9], [-2.10, -4.30, 1.4],
     [-1.35, 1.98, 0.3], [-2.33, -0.02, -0.1], [-1.17, -2.10, 0.2], [-0.20, -3.65, 1.3],
     [1.23, 1.81, 0.0], [3.39, 0.56, 0.0], [3.39, -1.93, 0.0], [1.25, -3.17, 0.0], [-3.12, 0.53, 0.0],
-    [-1.70, -5.25, 1.8], [-2.80, -4.55, 0.6], [-2.70, -3.85, 2.2]])
+    [-1.70, -5.25, 1.8], [-2.80, -4.55, 0.6], [-2.70, -3.85, 2.2]]) * 0.85  # compact: ~350 directed edges at r=5
 
 
 def md17_aspirin_batch(num_frames, jitter=0.05, seed=0):

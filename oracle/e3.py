@@ -244,7 +244,8 @@ def spherical_harmonics(lmax, vec, normalize=True, normalization="component"):
             math.sqrt(5.0 / 6.0) * (sh24 * z - sh20 * x),
         ]
     sh = torch.stack(out, dim=-1)
-    scale = torch.cat([torch.full((2 * l + 1,), math.sqrt(2 * l + 1)) for l in range(lmax + 1)]).to(sh)
+    scale = torch.cat([torch.full((2 * l + 1,), math.sqrt(2 * l + 1), dtype=sh.dtype, device=sh.device)
+                       for l in range(lmax + 1)])
     return sh * scale
 
 

@@ -1,0 +1,139 @@
+"""End-to-end parity of the MI355X models against the CPU oracle with identical weights and inputs.
+Bar (BASELINE.json north_star): energies (and forces) within 1e-4 relative, fp32, eval mode."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets as onets
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _pair(name, oracle_factory, irreps_in, **kw):
+    from equiformer_amd import nets
+    torch.manual_seed(0)
+    ref = oracle_factory(irreps_in, 5.0, **kw).eval()
+    mod = nets.model_entrypoint(name)(irreps_in=irreps_in, radius=5.0, **kw)
+    missing = mod.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return ref, mod.to(_dev()).eval()
+
+
+def test_qm9_forward_backward_parity():
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = _dev()
+    ref, mod = _pair("graph_attention_transformer_nonlinear_l2", onets.graph_attention_transformer_nonlinear_l2, "5x0e")
+    d = qm9_like_batch(8, 18, side=6.5, seed=0)
+    with torch.no_grad():
+        y64 = ref.double()(None, d["pos"].double(), d["batch"], d["z"])
+    ref = ref.float()
+    yr = ref(None, d["pos"], d["batch"], d["z"])
+    y = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
+    assert y.shape == (8, 1)
+    print("rel err vs fp32 oracle %.3e, vs fp64 oracle %.3e, fp32 oracle vs fp64 %.3e"
+          % (_rel(y, yr), _rel(y, y64), _rel(yr, y64)))
+    assert _rel(y, yr) < 1e-4 and _rel(y, y64) < 1e-4
+    # un-fused kernels give the same answer
+    mod.set_fused(False)
+    y2 = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
+    mod.set_fused(True)
+    assert _rel(y2, y64) < 1e-4
+    # backward: L1 loss as in engine.py:71, gradients of every parameter
+    tgt = d["y"]
+    loss_r = (yr.squeeze() - tgt).abs().mean()
+    loss = (y.squeeze() - tgt.to(dev)).abs().mean()
+    gr = torch.autograd.grad(loss_r, list(ref.parameters()), allow_unused=True)
+    gg = torch.autograd.grad(loss, list(mod.parameters()), allow_unused=True)
+    worst = 0.0
+    for (n, _), a, r in zip(ref.named_parameters(), gg, gr):
+        assert (a is None) == (r is None), n
+        if r is None or r.abs().max() == 0:
+            continue
+        e = _rel(a, r)
+        worst = max(worst, e)
+        assert e < 2e-3, (n, e)
+    print("worst parameter-gradient rel err %.3e" % worst)
+
+
+def test_qm9_train_step_runs_and_reduces_loss():
+    from equiformer_amd import nets
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = _dev()
+    torch.manual_seed(0)
+    mod = nets.model_entrypoint("graph_attention_transformer_nonlinear_l2")("5x0e", 5.0).to(dev).train()
+    d = {k: v.to(dev) for k, v in qm9_like_batch(16, 18, side=6.5, seed=1).items()}
+    opt = torch.optim.AdamW(mod.parameters(), lr=5e-4)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = (mod(None, d["pos"], d["batch"], d["z"]).squeeze() - d["y"]).abs().mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("name,fac", [("graph_attention_transformer_nonlinear_exp_l2_md17",
+                                       onets.graph_attention_transformer_nonlinear_exp_l2_md17),
+                                      ("graph_attention_transformer_nonlinear_exp_l3_md17",
+                                       onets.graph_attention_transformer_nonlinear_exp_l3_md17)])
+def test_md17_energy_and_forces_parity(name, fac):
+    from equiformer_amd.synthetic import md17_aspirin_batch
+    dev = _dev()
+    ref, mod = _pair(name, fac, "64x0e", num_basis=32)
+    d = md17_aspirin_batch(3, seed=0)
+    ref = ref.double()
+    Er, Fr = ref(d["z"], d["pos"].double(), d["batch"])
+    with torch.no_grad():  # the drivers evaluate under no_grad (main_md17.py:444)
+        E, F = mod(d["z"].to(dev), d["pos"].to(dev), d["batch"].to(dev))
+    assert E.shape == (3, 1) and F.shape == (63, 3)
+    print("%s: energy rel %.3e  force rel %.3e  mean|dF| %.3e" % (name, _rel(E, Er), _rel(F, Fr),
+                                                                  (F.double().cpu() - Fr.detach()).abs().mean().item()))
+    assert _rel(E, Er) < 1e-4 and _rel(F, Fr) < 1e-4
+
+
+def test_oc20_energy_parity():
+    from types import SimpleNamespace
+    from equiformer_amd import nets
+    dev = _dev()
+    torch.manual_seed(0)
+    ref = onets.oc20_l1_256_nonlinear().double().eval()
+    mod = nets.model_entrypoint("oc20_l1_256_nonlinear")()
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
+    mod = mod.to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    B, Na = 2, 40
+    pos = torch.rand(B * Na, 3, generator=g) * torch.tensor([8.0, 8.0, 10.0])
+    batch = torch.arange(B).repeat_interleave(Na)
+    Z = torch.randint(1, 84, (B * Na,), generator=g)
+    tags = torch.randint(0, 3, (B * Na,), generator=g)
+    # periodic images along x and y of an orthorhombic cell: explicit edge list + Cartesian offsets
+    src, dst, off = [], [], []
+    cell = torch.tensor([8.0, 8.0, 30.0])
+    for b in range(B):
+        idx = torch.arange(b * Na, (b + 1) * Na)
+        for sx in (-1, 0, 1):
+            for sy in (-1, 0, 1):
+                shift = torch.tensor([sx * cell[0], sy * cell[1], 0.0])
+                dvec = pos[idx][:, None, :] + shift - pos[idx][None, :, :]  # [src, dst]
+                dist = dvec.norm(dim=-1)
+                m = (dist < 5.0) & (dist > 1e-6)
+                s, t = m.nonzero(as_tuple=True)
+                src.append(idx[s]); dst.append(idx[t]); off.append(shift.expand(s.numel(), 3))
+    src, dst, off = torch.cat(src), torch.cat(dst), torch.cat(off)
+    yr = ref(Z, tags, pos.double(), batch, edge_index=torch.stack([src, dst]), offsets=off.double())
+    data = SimpleNamespace(pos=pos.to(dev), batch=batch.to(dev), atomic_numbers=Z.to(dev), tags=tags.to(dev),
+                           edge_index=torch.stack([src, dst]).to(dev), offsets=off.to(dev))
+    y = mod(data)
+    print("oc20 energy rel %.3e (E=%d edges)" % (_rel(y, yr), src.numel()))
+    assert _rel(y, yr) < 1e-4

@@ -1,0 +1,187 @@
+"""CPU-side checks of the host logic: registry / module tree / state_dict parity with the oracle, the C-ABI library
+loads and exports every declared symbol, layouts and path tables, and the product refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from equiformer_amd import lib
+    header = open(os.path.join(ROOT, "include", "equiformer_hip.h")).read()
+    declared = set(re.findall(r"\b(eqf_[a-z0-9_]+)\s*\(", header))
+    declared -= {"eqf_irreps", "eqf_rows", "eqf_dtp_paths"}
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(hip_lib, name), name
+    assert declared - {"eqf_version"} == set(lib.SIGNATURES), "ctypes table out of sync with the header"
+    assert lib.version().startswith("equiformer_hip")
+
+
+def test_struct_layouts_match_header():
+    from equiformer_amd import lib
+    assert ctypes.sizeof(lib.EqfIrreps) == 4 * (1 + 2 * lib.EQF_MAX_SEG)
+    assert ctypes.sizeof(lib.EqfDtpPaths) == 4 * (6 + 11 * lib.EQF_MAX_PATHS)
+    assert ctypes.sizeof(lib.EqfRows) == 12
+
+
+def test_argument_errors_are_reported_not_crashed(hip_lib):
+    from equiformer_amd import lib
+    rows = lib.EqfRows(1, 4, 0)
+    assert hip_lib.eqf_gemm_nn(None, rows, None, 4, None, rows, None, 4, 4, 4, 0, None) == -1
+    assert hip_lib.eqf_lnsilu_fwd(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 4, 128,
+                                  1e-5, None) == -2
+    with pytest.raises(lib.HipLibraryError):
+        lib.call("eqf_layernorm_fwd", None, None, None, None, None, None, 4, None, 1e-5, None)
+
+
+def test_registry_and_factories():
+    from equiformer_amd import nets
+    for name in ["graph_attention_transformer_nonlinear_l2", "graph_attention_transformer_nonlinear_exp_l2_md17",
+                 "graph_attention_transformer_nonlinear_exp_l3_md17", "graph_attention_transformer_l2",
+                 "graph_attention_transformer_nonlinear_l2_e3", "graph_attention_transformer_nonlinear_bessel_l2"]:
+        assert callable(nets.model_entrypoint(name))
+    with pytest.raises(KeyError):
+        nets.model_entrypoint("no_such_model")
+    # variants outside the hot path fail loudly instead of silently degrading
+    with pytest.raises(NotImplementedError):
+        nets.model_entrypoint("graph_attention_transformer_l2")("5x0e", 5.0)
+    with pytest.raises(NotImplementedError):
+        nets.model_entrypoint("graph_attention_transformer_nonlinear_bessel_l2")("5x0e", 5.0)
+    with pytest.raises(NotImplementedError):
+        nets.model_entrypoint("graph_attention_transformer_nonlinear_l2_e3")("5x0e", 5.0)
+
+
+@pytest.mark.parametrize("name,kw,count", [
+    ("graph_attention_transformer_nonlinear_l2", dict(irreps_in="5x0e", radius=5.0), 3531715),
+    ("graph_attention_transformer_nonlinear_exp_l2_md17", dict(irreps_in="64x0e", radius=5.0, num_basis=32), 3496001),
+    ("graph_attention_transformer_nonlinear_exp_l3_md17", dict(irreps_in="64x0e", radius=5.0, num_basis=32), 5500865),
+    ("oc20_l1_256_nonlinear", dict(), 9123331)])
+def test_parameter_counts_and_state_dict_keys(name, kw, count):
+    from equiformer_amd import nets
+    from oracle import nets as onets
+    m = nets.model_entrypoint(name)(**kw)
+    assert sum(p.numel() for p in m.parameters()) == count
+    ofac = dict(onets.ENTRYPOINTS, oc20_l1_256_nonlinear=lambda **k: onets.oc20_l1_256_nonlinear())[name]
+    o = ofac(**kw) if kw else ofac()
+    sm, so = m.state_dict(), o.state_dict()
+    assert list(sm.keys()) == list(so.keys())
+    for k in sm:
+        assert sm[k].shape == so[k].shape, k
+    if hasattr(m, "no_weight_decay"):
+        nwd = m.no_weight_decay()
+        assert "blocks.0.norm_1.affine_weight" in nwd and "rbf.mean" in nwd or "md17" in name or "oc20" in name
+        assert "blocks.0.ga.sep_act.dtp_rad.net.0.bias" in nwd and "blocks.0.ga.sep_act.dtp_rad.net.0.weight" not in nwd
+
+
+def test_appendix_a_keys_present():
+    from equiformer_amd import nets
+    sd = nets.model_entrypoint("graph_attention_transformer_nonlinear_l2")("5x0e", 5.0).state_dict()
+    expect = {"atom_embed.atom_type_lin.tp.weight": (640,), "atom_embed.atom_type_lin.bias.0": (128,),
+              "rbf.mean": (1, 128), "rbf.weight": (1, 1), "edge_deg_embed.exp.tp.weight": (128,),
+              "edge_deg_embed.rad.net.6.weight": (960, 64), "edge_deg_embed.rad.offset": (960,),
+              "edge_deg_embed.proj.tp.weight": (64512,), "blocks.0.norm_1.affine_weight": (224,),
+              "blocks.0.norm_1.affine_bias": (128,), "blocks.0.ga.merge_src.tp.weight": (21504,),
+              "blocks.0.ga.merge_src.bias.0": (128,), "blocks.0.ga.merge_dst.tp.weight": (21504,),
+              "blocks.0.ga.sep_act.lin.tp.weight": (86016,), "blocks.0.ga.sep_act.lin.bias.0": (224,),
+              "blocks.0.ga.sep_alpha.tp.weight": (28672,), "blocks.0.ga.sep_value.dtp.tp.weight": (960,),
+              "blocks.0.ga.sep_value.lin.tp.weight": (64512,), "blocks.0.ga.alpha_dot": (1, 4, 32),
+              "blocks.0.ga.proj.tp.weight": (21504,), "blocks.0.ffn.fctp_1.tp.weight": (101376,),
+              "blocks.0.ffn.fctp_1.bias.0": (672,), "blocks.4.ffn.fctp_2.tp.weight": (64512,),
+              "blocks.5.ffn.fctp_2.tp.weight": (196608,), "blocks.5.ffn_shortcut.tp.weight": (65536,),
+              "norm.affine_weight": (512,), "head.0.tp.weight": (262144,), "head.2.tp.weight": (512,),
+              "head.2.bias.0": (1,)}
+    for k, shp in expect.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert "blocks.0.ga.merge_dst.bias.0" not in sd
+
+
+def test_no_cpu_fallback():
+    from equiformer_amd import nets, ops
+    m = nets.model_entrypoint("graph_attention_transformer_nonlinear_l2")("5x0e", 5.0)
+    pos = torch.rand(6, 3)
+    with pytest.raises(ops.HipOnlyError):
+        m(None, pos, torch.zeros(6, dtype=torch.long), torch.tensor([1, 6, 6, 8, 1, 1]))
+    with pytest.raises(ops.HipOnlyError):
+        ops.dense_linear(torch.rand(4, 4), torch.rand(4, 4), None)
+
+
+def test_product_never_imports_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; import equiformer_amd, equiformer_amd.nets, equiformer_amd.ops, equiformer_amd.graph, "
+            "equiformer_amd.parallel, equiformer_amd.synthetic; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'")
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "equiformer_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_layout_permutations_roundtrip():
+    from equiformer_amd.layout import RowLayout
+    lay = RowLayout("8x0e+4x1e+2x2e")
+    assert lay.dim == 8 + 12 + 10 and lay.offsets == [0, 8, 20]
+    x = torch.arange(lay.dim, dtype=torch.float32)[None]
+    cf = x[:, lay.perm_from_e3nn()]
+    assert torch.equal(cf[:, lay.perm_to_e3nn()], x)
+    # e3nn element (seg 1, u=2, m=1) sits at 8 + 2*3 + 1; in CF at 8 + 1*4 + 2
+    assert cf[0, 8 + 1 * 4 + 2].item() == 8 + 2 * 3 + 1
+    with pytest.raises(NotImplementedError):
+        RowLayout("8x0e+4x1o")
+
+
+def test_dtp_table_matches_oracle_instructions():
+    from equiformer_amd.layout import DtpTable
+    from oracle import nets as onets
+    for irr, sh in [("128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e"), ("128x0e+64x1e+64x2e+32x3e", "1x0e+1x1e+1x2e+1x3e"),
+                    ("256x0e+128x1e", "1x0e+1x1e")]:
+        t = DtpTable(irr, sh, irr)
+        o = onets.DepthwiseTensorProduct(irr, sh, irr, bias=False)
+        assert t.weight_numel == o.tp.weight_numel and len(t.paths) == len(o.tp.instructions)
+        assert repr(t.irreps_out) == repr(o.irreps_out.simplify())
+        assert repr(t.irreps_out_unsimplified) == repr(o.irreps_out)
+        slices = o.irreps_out.slices()
+        for p, (i1, i2, io, *_rest) in zip(t.paths, o.tp.instructions):
+            assert (p["l1"], p["l2"], p["l3"]) == (o.irreps_in1[i1][1].l, o.irreps_in2[i2][1].l, o.irreps_out[io][1].l)
+            # first element of the path's output slice in e3nn order <-> (out_off, out_ch) in CF order
+            seg_start = sum(m * ir.dim for m, ir in o.irreps_out.simplify() if ir.l < p["l3"])
+            assert p["out_off"] == seg_start
+            assert slices[io].start == seg_start + p["out_ch"] * (2 * p["l3"] + 1)
+    assert DtpTable("128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "128x0e+64x1e+32x2e").m_numel == 179
+
+
+def test_so3_matches_oracle_and_constants():
+    import numpy as np
+    from equiformer_amd import so3
+    from oracle import e3, nets as onets
+    for l1 in range(4):
+        for l2 in range(4):
+            for l3 in range(abs(l1 - l2), min(3, l1 + l2) + 1):
+                assert np.abs(so3.wigner_3j(l1, l2, l3) - e3.wigner_3j(l1, l2, l3).numpy()).max() < 1e-12
+    assert abs(so3.C_SILU - e3.normalize2mom_const(torch.nn.functional.silu)) < 1e-12
+    assert abs(so3.C_SIGMOID - e3.normalize2mom_const(torch.sigmoid)) < 1e-12
+    assert abs(so3.C_SMOOTH_LEAKY_RELU_02 - e3.normalize2mom_const(onets.SmoothLeakyReLU(0.2))) < 1e-12
+
+
+def test_synthetic_batches_have_the_survey_statistics():
+    from equiformer_amd.synthetic import md17_aspirin_batch, qm9_like_batch
+    from oracle import nets as onets
+    d = qm9_like_batch(32, 18, side=6.5, seed=0)
+    src, _ = onets.radius_graph(d["pos"], 5.0, d["batch"])
+    assert 170 < src.numel() / 32 < 230          # "~200 edges" per molecule (198 +- 21)
+    d = qm9_like_batch(32, 18, side=5.0, seed=0)
+    src, _ = onets.radius_graph(d["pos"], 5.0, d["batch"])
+    assert 255 < src.numel() / 32 < 300          # QM9 statistics point (~277)
+    a = md17_aspirin_batch(2)
+    assert a["pos"].shape == (42, 3) and sorted(a["z"][:21].tolist()) == [1] * 8 + [6] * 9 + [8] * 4
+    src, _ = onets.radius_graph(a["pos"], 5.0, a["batch"])
+    assert 320 < src.numel() / 2 <= 420
+    dmin = torch.cdist(a["pos"][:21], a["pos"][:21]) + 10 * torch.eye(21)
+    assert dmin.min() > 0.7

@@ -1,0 +1,163 @@
+"""Known-answer tests that pin the oracle's e3nn-0.4.4 conventions (KAT-1..KAT-9).
+The reference ships no golden vectors, so these analytic identities are what anchors parity."""
+import math
+
+import pytest
+import torch
+
+from oracle import e3, nets
+
+SL = [slice(0, 1), slice(1, 4), slice(4, 9), slice(9, 16)]
+
+
+def test_kat1_w3j_values():
+    assert abs(e3.wigner_3j(1, 1, 1)[0, 1, 2].item() - 1 / math.sqrt(6)) < 1e-12
+    for l in range(4):
+        eye = torch.eye(2 * l + 1, dtype=torch.float64) / math.sqrt(2 * l + 1)
+        assert (e3.wigner_3j(l, l, 0)[:, :, 0] - eye).abs().max() < 1e-12
+        assert (e3.wigner_3j(0, l, l)[0] - eye).abs().max() < 1e-12
+    for t in [(1, 1, 1), (2, 1, 2), (3, 2, 2), (1, 2, 3)]:
+        assert abs(e3.wigner_3j(*t).norm().item() - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("abc,rho", [((1, 1, 0), math.sqrt(3)), ((1, 1, 2), 0.489898), ((1, 2, 1), 0.816497),
+                                     ((1, 2, 3), 0.428571), ((1, 3, 2), 0.6), ((2, 2, 0), math.sqrt(5)),
+                                     ((2, 2, 2), 0.534522), ((2, 3, 1), 1.0), ((2, 3, 3), 0.436436),
+                                     ((3, 3, 0), math.sqrt(7)), ((3, 3, 2), 0.611010)])
+def test_kat2_sh_w3j_consistency(abc, rho):
+    a, b, c = abc
+    g = torch.Generator().manual_seed(1)
+    Y = e3.spherical_harmonics(3, torch.randn(7, 3, generator=g, dtype=torch.float64))
+    r = torch.einsum("ijk,zi,zj->zk", e3.wigner_3j(a, b, c), Y[:, SL[a]], Y[:, SL[b]])
+    assert (r - rho * Y[:, SL[c]]).abs().max() < 2e-6
+
+
+def test_kat3_sh_norm():
+    g = torch.Generator().manual_seed(2)
+    Y = e3.spherical_harmonics(3, torch.randn(9, 3, generator=g, dtype=torch.float64))
+    for l in range(4):
+        assert (Y[:, SL[l]].pow(2).sum(-1) - (2 * l + 1)).abs().max() < 1e-12
+
+
+def test_w3j_rotation_invariance():
+    """C is invariant under D^l1 x D^l2 x D^l3 with D^l obtained from the SH themselves (Y(Rx) = D Y(x))."""
+    g = torch.Generator().manual_seed(3)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    x = torch.randn(64, 3, generator=g, dtype=torch.float64)
+    Y, YR = e3.spherical_harmonics(3, x), e3.spherical_harmonics(3, x @ q.T)
+    D = [torch.linalg.lstsq(Y[:, SL[l]], YR[:, SL[l]]).solution.T for l in range(4)]
+    for t in [(1, 1, 1), (1, 2, 2), (2, 2, 2), (2, 1, 3), (3, 3, 2)]:
+        C = e3.wigner_3j(*t)
+        Cr = torch.einsum("ia,jb,kc,abc->ijk", D[t[0]], D[t[1]], D[t[2]], C)
+        assert (C - Cr).abs().max() < 1e-9
+
+
+def test_normalize2mom_constants():
+    assert abs(e3.normalize2mom_const(torch.nn.functional.silu) - 1.6791767924) < 1e-8
+    assert abs(e3.normalize2mom_const(torch.sigmoid) - 1.8467055342) < 1e-8
+    assert abs(e3.normalize2mom_const(nets.SmoothLeakyReLU(0.2)) - 1.5313204756) < 1e-8
+
+
+def test_kat4_parameter_counts():
+    n = lambda m: sum(p.numel() for p in m.parameters())
+    assert n(nets.graph_attention_transformer_nonlinear_l2("5x0e", 5.0)) == 3531715
+    assert n(nets.graph_attention_transformer_nonlinear_exp_l2_md17("64x0e", 5.0, num_basis=32)) == 3496001
+    assert n(nets.graph_attention_transformer_nonlinear_exp_l3_md17("64x0e", 5.0, num_basis=32)) == 5500865
+    assert n(nets.oc20_l1_256_nonlinear()) == 9123331
+
+
+def test_kat5_dtp_structure():
+    d = nets.DepthwiseTensorProduct("128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "128x0e+64x1e+32x2e", bias=False)
+    assert len(d.tp.instructions) == 15 and d.tp.weight_numel == 960
+    assert repr(d.irreps_out.simplify()) == "224x0e+384x1e+352x2e"
+    paths = [(d.irreps_in1[i][1].l, d.irreps_in2[j][1].l, d.irreps_out[k][1].l) for i, j, k, *_ in d.tp.instructions]
+    assert paths == [(0, 0, 0), (0, 1, 1), (0, 2, 2), (1, 0, 1), (1, 1, 0), (1, 1, 1), (1, 1, 2), (1, 2, 1), (1, 2, 2),
+                     (2, 0, 2), (2, 1, 1), (2, 1, 2), (2, 2, 0), (2, 2, 1), (2, 2, 2)]
+    d3 = nets.DepthwiseTensorProduct("128x0e+64x1e+64x2e+32x3e", "1x0e+1x1e+1x2e+1x3e", "128x0e+64x1e+64x2e+32x3e",
+                                     bias=False)
+    assert len(d3.tp.instructions) == 34 and d3.tp.weight_numel == 2112
+    assert repr(d3.irreps_out.simplify()) == "288x0e+576x1e+672x2e+576x3e"
+
+
+def test_linear_rs_is_plain_matmul():
+    torch.manual_seed(0)
+    lin = nets.LinearRS(e3.Irreps("8x0e+4x1e"), e3.Irreps("6x0e+2x1e"), bias=False).double()
+    x = torch.randn(5, 20, dtype=torch.float64)
+    w = lin.tp.weight
+    W0, W1 = w[:48].view(8, 6), w[48:].view(4, 2)
+    ref = torch.cat([x[:, :8] @ W0, torch.einsum("zui,uw->zwi", x[:, 8:].view(5, 4, 3), W1).reshape(5, 6)], 1)
+    assert (lin(x) - ref).abs().max() < 1e-12
+
+
+def _small_qm9(**kw):
+    cfg = dict(irreps_in="5x0e", irreps_node_embedding="32x0e+32x1e+32x2e", num_layers=2, irreps_sh="1x0e+1x1e+1x2e",
+               max_radius=5.0, number_of_basis=16, fc_neurons=[64, 64], irreps_feature="64x0e",
+               irreps_head="8x0e+8x1e+8x2e", num_heads=4, nonlinear_message=True,
+               irreps_mlp_mid="64x0e+32x1e+32x2e", alpha_drop=0.0)
+    cfg.update(kw)
+    return cfg
+
+
+def _rot(gen):
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=gen, dtype=torch.float64))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def test_kat6_kat8_equivariance_and_permutation():
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(4)
+    m = nets.GraphAttentionTransformer(**_small_qm9()).double().eval()
+    B, Na = 3, 9
+    pos = torch.rand(B * Na, 3, generator=g, dtype=torch.float64) * 4.0
+    batch = torch.arange(B).repeat_interleave(Na)
+    z = torch.tensor([1, 6, 7, 8, 9])[torch.randint(0, 5, (B * Na,), generator=g)]
+    y = m(None, pos, batch, z)
+    R = _rot(g)
+    assert (y - m(None, pos @ R.T + 0.7, batch, z)).abs().max() < 1e-10
+    p = torch.cat([torch.randperm(Na, generator=g), torch.arange(Na, B * Na)])
+    assert (y - m(None, pos[p], batch[p], z[p])).abs().max() < 1e-10
+
+
+def test_kat6_kat7_md17_forces():
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(5)
+    cfg = _small_qm9(irreps_in="64x0e", basis_type="exp")
+    m = nets.GraphAttentionTransformerMD17(**cfg).double().eval()
+    B, Na = 2, 8
+    pos = torch.rand(B * Na, 3, generator=g, dtype=torch.float64) * 3.5
+    batch = torch.arange(B).repeat_interleave(Na)
+    z = torch.randint(1, 9, (B * Na,), generator=g)
+    E, F = m(z, pos.clone(), batch)
+    R = _rot(g)
+    E2, F2 = m(z, (pos @ R.T).clone(), batch)
+    assert (E - E2).abs().max() < 1e-10 and (F @ R.T - F2).abs().max() < 1e-9
+    eps = 1e-5
+    for (i, d) in [(0, 0), (5, 1), (11, 2)]:
+        pp, pm = pos.clone(), pos.clone()
+        pp[i, d] += eps
+        pm[i, d] -= eps
+        fd = -((m(z, pp, batch)[0] - m(z, pm, batch)[0]).sum() / (2 * eps)).item()
+        assert abs(fd - F[i, d].item()) < 1e-6 * max(1.0, abs(fd))
+
+
+def test_kat9_segment_softmax():
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(12, 4, generator=g, dtype=torch.float64)
+    idx = torch.tensor([0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2])
+    a = nets.segment_softmax(x, idx, 3)
+    assert (nets.scatter_sum(a, idx, 3) - 1).abs().max() < 1e-12
+    assert (a[:4] - torch.softmax(x[:4], 0)).abs().max() < 1e-12
+
+
+def test_radius_graph_order():
+    g = torch.Generator().manual_seed(7)
+    pos = torch.rand(14, 3, generator=g) * 4
+    batch = torch.tensor([0] * 6 + [1] * 8)
+    src, dst = nets.radius_graph(pos, 2.5, batch)
+    assert (dst[1:] >= dst[:-1]).all() and (batch[src] == batch[dst]).all() and (src != dst).all()
+    same = dst[1:] == dst[:-1]
+    assert (src[1:][same] > src[:-1][same]).all()
