@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""Headline benchmark: molecules/sec of a full QM9 train step (graph_attention_transformer_nonlinear_l2, L_max=2,
+6 blocks, fp32) on N MI355X, data-parallel over molecules, plus the roofline of the dominant kernel and the CPU
+oracle timed on the host cores.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = graph construction from positions + forward + L1 loss + backward + (N>1: ONE flat-gradient RCCL
+all-reduce) + AdamW update, on a synthetic QM9-shaped batch already resident in HBM (128 molecules x 18 atoms per
+GPU, ~200 directed edges per molecule at r = 5 A).  Weak scaling: per-GPU batch fixed.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODEL = "graph_attention_transformer_nonlinear_l2"
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32)
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="molecules per GPU (reference script: 128)")
+    ap.add_argument("--atoms", type=int, default=18)
+    ap.add_argument("--side", type=float, default=6.5, help="cube edge of the synthetic molecules (6.5 -> ~200 edges)")
+    ap.add_argument("--dominant", default="gemm_rows_128x128_dtp_kn",
+                    help="kernel (name substring) timed with HIP events for the roofline line")
+    ap.add_argument("--cpu-molecules", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_optimizer(model, lr=5e-4, weight_decay=5e-3):
+    """AdamW with the reference's name-based no-weight-decay groups (optim_factory.py:27-42)."""
+    skip = model.no_weight_decay()
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if (name.endswith(".bias") or name.endswith(".affine_weight") or name.endswith(".affine_bias")
+                or name.endswith(".mean_shift") or "bias." in name or name in skip):
+            no_decay.append(p)
+        else:
+            decay.append(p)
+    groups = [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+    fused = all(p.is_cuda for p in model.parameters())
+    return torch.optim.AdamW(groups, lr=lr, fused=fused)
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference, plain torch fp32) doing the same train step on the host cores,
+    on a bounded sample of the workload (same molecule shape, smaller batch)."""
+    from equiformer_amd.synthetic import qm9_like_batch
+    from oracle import nets as onets
+    # the oracle's tensors are small (8 molecules): more than ~16 threads only adds synchronisation cost
+    cores = min(os.cpu_count() or 1, args.cpu_threads)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = onets.graph_attention_transformer_nonlinear_l2("5x0e", 5.0).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=5e-3)
+    d = qm9_like_batch(args.cpu_molecules, args.atoms, side=args.side, seed=0)
+
+    def step():
+        opt.zero_grad()
+        loss = (model(None, d["pos"], d["batch"], d["z"]).squeeze() - d["y"]).abs().mean()
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while done < args.cpu_steps and (done == 0 or time.perf_counter() - t0 < 30.0):
+        step()
+        done += 1
+    dt = (time.perf_counter() - t0) / done
+    args.cpu_steps = done
+    return {"value": args.cpu_molecules / dt, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps of %d molecules x %d atoms (oracle, torch fp32 CPU, %d threads), %.2f s/step"
+                      % (args.cpu_steps, args.cpu_molecules, args.atoms, cores, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from equiformer_amd import lib, nets
+    from equiformer_amd.parallel import FlatGradAllReduce
+    from equiformer_amd.synthetic import qm9_like_batch
+    lib.load()
+
+    torch.manual_seed(0)
+    model = nets.model_entrypoint(MODEL)(irreps_in="5x0e", radius=5.0, num_basis=128).to(dev).train()
+    reducer = FlatGradAllReduce(model)
+    reducer.broadcast_parameters()
+    opt = make_optimizer(model)
+    d = {k: v.to(dev) for k, v in qm9_like_batch(args.batch, args.atoms, side=args.side, seed=1000 + rank).items()}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred = model(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"])
+        loss = (pred.squeeze() - d["y"]).abs().mean()  # L1Loss (main_qm9.py:188-189)
+        loss.backward()
+        if world > 1:
+            reducer.reduce()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # graph size of this rank's batch (for the record)
+    from equiformer_amd.graph import EdgeGraph
+    g = EdgeGraph.from_radius(d["pos"], d["batch"], 5.0)
+    n_nodes, n_edges = g.N, g.E
+
+    lib.prof_enable(args.dominant)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = lib.prof_report()
+    lib.prof_enable(None)
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = t.item()
+
+    if rank == 0:
+        out = {
+            "metric": "molecules/sec (train step) QM9 L_max=2, 6 blocks",
+            "value": args.batch * world * args.steps / dt,
+            "unit": "molecules/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "QM9 %s train step (radius graph + fwd + L1 + bwd + AdamW), %d molecules/GPU x %d atoms, "
+                            "r=5.0, num_basis=128, alpha_drop=0.2" % (MODEL, args.batch, args.atoms),
+                "global_batch": args.batch * world, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
+                "edges_per_molecule": n_edges / args.batch, "parallelism": "dp%d" % world,
+                "final_loss": float(loss.item()),
+            },
+        }
+        rec = None
+        for name, r in prof.items():
+            if rec is None or r["total_ms"] > rec[1]["total_ms"]:
+                rec = (name, r)
+        if rec is not None:
+            name, r = rec
+            avg_ms = r["total_ms"] / r["launches"]
+            tflops = r["flops"] / r["total_ms"] / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel": name,
+                               "launches": r["launches"], "avg_launch_ms": avg_ms,
+                               "flops_per_launch": r["flops"] / r["launches"],
+                               "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
+        print("[bench] gpu part done: %.1f molecules/s, %.2f ms/step" % (out["value"], out["ms_per_step"]),
+              file=sys.stderr, flush=True)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

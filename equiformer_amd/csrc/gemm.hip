@@ -14,6 +14,8 @@
 // conflict-free ds_read_b32; sources that are contiguous along k are transposed while staging (odd row stride),
 // sources contiguous along x are staged with ds_write_b128 (stride = 4 mod 8 floats).
 #include "common.h"
+#include "prof.h"
+#include <cstdio>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -340,16 +342,26 @@ template <int AMODE, int BMODE>
 int launch_rows(RowsArgs& a, hipStream_t st) {
   const int mt = eqf_cdiv(a.M, a.rows_per_tile);
   if (a.M <= 0 || a.N <= 0) return 0;
-  if (a.N > 64) {
+  const int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+  char name[96];
+  snprintf(name, sizeof name, "gemm_rows_128x%d_%s_%s", bn, AMODE == A_DTP ? "dtp" : "mem", BMODE == B_KN ? "kn" : "nk");
+  // algorithmic bytes: A (or the DTP inputs x,w,coupling) + B + C, each once
+  const double a_bytes = AMODE == A_DTP
+                             ? 4.0 * (double)(a.M / a.dtp.d3) * (a.dtp.x_ld + (a.dtp.w ? a.dtp.w_ld : 0) + a.dtp.m_ld)
+                             : 4.0 * (double)a.M * a.K;
+  const int pid = eqf_prof_begin(name, st, 2.0 * a.M * (double)a.N * a.K,
+                                 a_bytes + 4.0 * (double)a.K * a.N + 4.0 * (double)a.M * a.N);
+  if (bn == 128) {
     dim3 grid(mt, eqf_cdiv(a.N, 128));
     hipLaunchKernelGGL((gemm_rows_kernel<128, 128, 2, 2, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
-  } else if (a.N > 32) {
+  } else if (bn == 64) {
     dim3 grid(mt, 1);
     hipLaunchKernelGGL((gemm_rows_kernel<128, 64, 2, 2, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
   } else {
     dim3 grid(mt, 1);
     hipLaunchKernelGGL((gemm_rows_kernel<128, 32, 4, 1, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
   }
+  eqf_prof_end(pid, st);
   EQF_CHECK_LAUNCH();
   return 0;
 }
@@ -370,6 +382,13 @@ int launch_tn(TnArgs& a, hipStream_t st) {
   a.steps_per_split = eqf_cdiv(total_steps, ksplit);
   ksplit = eqf_cdiv(total_steps, a.steps_per_split);
   dim3 grid(eqf_cdiv(a.M, BMv), eqf_cdiv(a.N, BNv), ksplit);
+  char name[96];
+  snprintf(name, sizeof name, "gemm_tn_%dx%d_%s", BMv, BNv, AMODE == A_DTP ? "dtp" : "mem");
+  const double a_bytes = AMODE == A_DTP
+                             ? 4.0 * (double)(a.R / a.dtp.d3) * (a.dtp.x_ld + (a.dtp.w ? a.dtp.w_ld : 0) + a.dtp.m_ld)
+                             : 4.0 * (double)a.R * a.M;
+  const int pid = eqf_prof_begin(name, st, 2.0 * a.M * (double)a.N * a.R,
+                                 a_bytes + 4.0 * (double)a.R * a.N + 4.0 * (double)a.M * a.N);
   if (bm64 && bn64)
     hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 2, 2, 1, AMODE>), grid, dim3(NTHREADS), 0, st, a);
   else if (bm64)
@@ -378,6 +397,7 @@ int launch_tn(TnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((gemm_tn_kernel<32, 64, 1, 2, 2, AMODE>), grid, dim3(NTHREADS), 0, st, a);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<32, 32, 1, 1, 4, AMODE>), grid, dim3(NTHREADS), 0, st, a);
+  eqf_prof_end(pid, st);
   EQF_CHECK_LAUNCH();
   return 0;
 }

@@ -78,6 +78,8 @@ SIGNATURES = {
     "eqf_alpha_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
     "eqf_attn_aggregate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp],
     "eqf_attn_aggregate_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp],
+    "eqf_prof_enable": [ctypes.c_char_p],
+    "eqf_prof_report": [ctypes.c_char_p, c_int],
 }
 
 _lib = None
@@ -115,6 +117,23 @@ def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise HipLibraryError("%s failed with code %d" % (name, rc))
+
+
+def prof_enable(filter_substring):
+    """None disables; "" records every matrix-core launch; otherwise only kernels whose name contains the string."""
+    load().eqf_prof_enable(None if filter_substring is None else filter_substring.encode())
+
+
+def prof_report():
+    """{kernel name: dict(launches, total_ms, flops, bytes)} for the launches recorded since the last call."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = load().eqf_prof_report(buf, len(buf))
+    out = {}
+    if n > 0:
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms, fl, by = line.split()
+            out[name] = dict(launches=int(float(cnt)), total_ms=float(ms), flops=float(fl), bytes=float(by))
+    return out
 
 
 def make_irreps(segments):

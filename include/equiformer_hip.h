@@ -259,6 +259,17 @@ int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* ro
                            const eqf_irreps* irreps, float drop_p, unsigned long long seed,
                            void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement hooks (no reference counterpart; used by bench.py for the roofline line)
+ * ------------------------------------------------------------------------------------------- */
+
+/* filter == NULL: stop recording.  Otherwise record a HIP-event pair (on the launch stream) around every
+ * matrix-core kernel launch whose name contains `filter` ("" = all). */
+int eqf_prof_enable(const char* filter);
+/* Wait for the recorded events; write "name launches total_ms algorithmic_flops algorithmic_bytes\n" per kernel
+ * into buf (host memory); clears the records.  Returns bytes written or < 0. */
+int eqf_prof_report(char* buf, int buflen);
+
 #ifdef __cplusplus
 }
 #endif
