@@ -13,6 +13,9 @@
 // LDS tiles are stored k-major (T[k][x]) so that the MFMA operand fetch (lane = x, one k per half-wave) is a
 // conflict-free ds_read_b32; sources that are contiguous along k are transposed while staging (odd row stride),
 // sources contiguous along x are staged with ds_write_b128 (stride = 4 mod 8 floats).
+// The K loop is software pipelined: the global loads of step k+1 are issued before the MFMAs of step k, so that
+// HBM/L2 latency hides behind the 64-cycle fp32 MFMAs even at one or two workgroups per CU (graphs here are small:
+// ~25 k edges per 128-molecule batch, i.e. only a few hundred row tiles per launch).
 #include "common.h"
 #include "prof.h"
 #include <cstdio>
@@ -23,7 +26,10 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
-constexpr int MAX_SLABS = 32;  // K (channels of one DTP output degree) <= 1024
+constexpr int MAX_SLABS = 32;   // K (channels of one DTP output degree) <= 1024
+constexpr int ROWS_PAIRS = 8;   // (edge, channel) pairs generated per thread and K step in the rows kernel (<= 64 edges / tile)
+constexpr int TN_PAIRS = 4;     // ... in the tn kernel (<= 32 edges per reduction step)
+constexpr int MAX_MTILE = 6656; // floats of coupling staged in LDS per row tile
 
 struct Rows {
   const float* base;
@@ -35,7 +41,7 @@ struct DtpSlab {  // one 32-channel slab of the generated A operand
   int x_off;      // offset of (segment l1, channel u0) in the x row
   int x_mul;      // multiplicity of that segment (stride between components i)
   int w_off;      // offset of the slab's weights in the w row
-  int m_off;      // offset of the path's coupling matrix in the coupling row
+  int m_off;      // offset of the path's coupling matrix inside the degree-l3 block of the coupling row
 };
 
 struct DtpA {
@@ -43,117 +49,145 @@ struct DtpA {
   const float* coupling;
   const float* w;  // may be null
   int x_ld, m_ld, w_ld;
-  int d3;   // 2*l3+1
-  int ept;  // edges per tile (rows kernel: per M tile; tn kernel: per reduction step)
+  int d3;      // 2*l3+1
+  int ept;     // edges per tile (rows kernel: per M tile; tn kernel: per reduction step)
+  int m_base;  // start of the degree-l3 block in the coupling row
+  int m_len;   // its length
   DtpSlab slabs[MAX_SLABS];
 };
 
 // ------------------------------------------------------------------------------------------------
-// LDS staging
+// operand loaders: issue() = global -> registers (for the NEXT K step), commit() = registers -> LDS
 // ------------------------------------------------------------------------------------------------
 // source rows run over the tile's x index and are contiguous along k  ->  T[k][x], SX odd
 template <int BX, int SX>
-__device__ __forceinline__ void fill_contigk(float* __restrict__ T, const Rows& R, int x0, int xcnt, int k0, int K,
-                                             bool vec) {
-  const int t = threadIdx.x;
-  const int kq = t & 7, xr0 = t >> 3;
+struct LoaderContigK {
+  float4 v[BX / 32];
+  __device__ __forceinline__ void issue(const Rows& R, int x0, int xcnt, int k0, int K, bool vec) {
+    const int t = threadIdx.x;
+    const int kq = t & 7, xr0 = t >> 3;
 #pragma unroll
-  for (int pass = 0; pass < BX / 32; ++pass) {
-    const int xr = xr0 + pass * 32;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int krem = K - (k0 + kq * 4);
-    if (xr < xcnt && krem > 0) {
-      const float* p = R.base + row_off2(x0 + xr, R.d, R.ld, R.inner) + k0 + kq * 4;
-      if (vec && krem >= 4) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        v.x = p[0];
-        if (krem > 1) v.y = p[1];
-        if (krem > 2) v.z = p[2];
-        if (krem > 3) v.w = p[3];
+    for (int pass = 0; pass < BX / 32; ++pass) {
+      const int xr = xr0 + pass * 32;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int krem = K - (k0 + kq * 4);
+      if (xr < xcnt && krem > 0) {
+        const float* p = R.base + row_off2(x0 + xr, R.d, R.ld, R.inner) + k0 + kq * 4;
+        if (vec && krem >= 4) {
+          r = *reinterpret_cast<const float4*>(p);
+        } else {
+          r.x = p[0];
+          if (krem > 1) r.y = p[1];
+          if (krem > 2) r.z = p[2];
+          if (krem > 3) r.w = p[3];
+        }
       }
+      v[pass] = r;
     }
-    float* q = T + (kq * 4) * SX + xr;
-    q[0] = v.x;
-    q[SX] = v.y;
-    q[2 * SX] = v.z;
-    q[3 * SX] = v.w;
   }
-}
+  __device__ __forceinline__ void commit(float* __restrict__ T) const {
+    const int t = threadIdx.x;
+    const int kq = t & 7, xr0 = t >> 3;
+#pragma unroll
+    for (int pass = 0; pass < BX / 32; ++pass) {
+      float* q = T + (kq * 4) * SX + xr0 + pass * 32;
+      q[0] = v[pass].x;
+      q[SX] = v[pass].y;
+      q[2 * SX] = v[pass].z;
+      q[3 * SX] = v[pass].w;
+    }
+  }
+};
 
 // source rows run over the reduction index k (two-level) and are contiguous along x  ->  T[k][x], SX % 4 == 0
 template <int BX, int SX>
-__device__ __forceinline__ void fill_natural(float* __restrict__ T, const Rows& R, int k0, int kcnt, int x0, int X,
-                                             bool vec) {
-  constexpr int XQ = BX / 4;
-  constexpr int RPP = NTHREADS / XQ;
-  const int t = threadIdx.x;
-  const int xq = t % XQ, kr0 = t / XQ;
+struct LoaderNatural {
+  static constexpr int XQ = BX / 4;
+  static constexpr int RPP = NTHREADS / XQ;
+  static constexpr int NP = BK / RPP;
+  float4 v[NP];
+  __device__ __forceinline__ void issue(const Rows& R, int k0, int kcnt, int x0, int X, bool vec) {
+    const int t = threadIdx.x;
+    const int xq = t % XQ, kr0 = t / XQ;
 #pragma unroll
-  for (int pass = 0; pass < BK / RPP; ++pass) {
-    const int kr = kr0 + pass * RPP;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int x = x0 + xq * 4;
-    const int xrem = X - x;
-    if (kr < kcnt && xrem > 0) {
-      const float* p = R.base + row_off2(k0 + kr, R.d, R.ld, R.inner) + x;
-      if (vec && xrem >= 4) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        v.x = p[0];
-        if (xrem > 1) v.y = p[1];
-        if (xrem > 2) v.z = p[2];
-        if (xrem > 3) v.w = p[3];
+    for (int pass = 0; pass < NP; ++pass) {
+      const int kr = kr0 + pass * RPP;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int x = x0 + xq * 4;
+      const int xrem = X - x;
+      if (kr < kcnt && xrem > 0) {
+        const float* p = R.base + row_off2(k0 + kr, R.d, R.ld, R.inner) + x;
+        if (vec && xrem >= 4) {
+          r = *reinterpret_cast<const float4*>(p);
+        } else {
+          r.x = p[0];
+          if (xrem > 1) r.y = p[1];
+          if (xrem > 2) r.z = p[2];
+          if (xrem > 3) r.w = p[3];
+        }
+      }
+      v[pass] = r;
+    }
+  }
+  __device__ __forceinline__ void commit(float* __restrict__ T) const {
+    const int t = threadIdx.x;
+    const int xq = t % XQ, kr0 = t / XQ;
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) *reinterpret_cast<float4*>(T + (kr0 + pass * RPP) * SX + xq * 4) = v[pass];
+  }
+};
+
+// DTP-generated operand: thread owns channel u = t & 31 of the slab and the edges el = (t >> 5) + 8 p.
+// issue(): loads w[e, slab, u] and x[e, l1, 0..d1), u] of every owned edge (coalesced over u).
+// commit(): out[el, m3] = w * sum_i M[el][i, m3] * x[i], with the tile's coupling block M read from LDS.
+template <int NP>
+struct LoaderDtp {
+  float w[NP];
+  float xv[NP][7];
+  DtpSlab s;
+  __device__ __forceinline__ void issue(const DtpA& D, int slab, int e0, int ecnt) {
+    s = D.slabs[slab];
+    const int u = threadIdx.x & 31, g = threadIdx.x >> 5;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int el = g + 8 * p;
+      if (el < ecnt) {
+        const long e = e0 + el;
+        w[p] = D.w ? D.w[e * D.w_ld + s.w_off + u] : 1.0f;
+        const float* xp = D.x + e * D.x_ld + s.x_off + u;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) xv[p][i] = (i < s.d1) ? xp[i * s.x_mul] : 0.f;
       }
     }
-    *reinterpret_cast<float4*>(T + kr * SX + xq * 4) = v;
   }
-}
-
-// value of the DTP output for (edge e, slab channel u), all d3 components, written through `put(m3, value)`
-template <typename Put>
-__device__ __forceinline__ void dtp_generate(const DtpA& D, const DtpSlab& s, long e, int u, Put put) {
-  const float wv = D.w ? D.w[e * D.w_ld + s.w_off + u] : 1.0f;
-  const float* xp = D.x + e * D.x_ld + s.x_off + u;
-  const float* mp = D.coupling + e * D.m_ld + s.m_off;
-  float xv[7];
+  // rows kernel: As[u][el*d3 + m3]   (row_stride = 1, col_stride = SA)
+  // tn kernel  : As[el*d3 + m3][sl*32 + u]   (row_stride = SA, col_stride = 1, col0 = sl*32)
+  __device__ __forceinline__ void commit(float* __restrict__ T, const float* __restrict__ Mt, int m_stride, int d3,
+                                         int ecnt, int row_stride, int col_stride, int col0) const {
+    const int u = threadIdx.x & 31, g = threadIdx.x >> 5;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) xv[i] = (i < s.d1) ? xp[i * s.x_mul] : 0.f;
-  for (int m3 = 0; m3 < D.d3; ++m3) {
-    float acc = 0.f;
+    for (int p = 0; p < NP; ++p) {
+      const int el = g + 8 * p;
+      if (el < ecnt) {
+        const float* mp = Mt + (long)el * m_stride + s.m_off;
+        float* q = T + (col0 + u) * col_stride + (el * d3) * row_stride;
+        for (int m3 = 0; m3 < d3; ++m3) {
+          float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
-      if (i < s.d1) acc = fmaf(mp[i * D.d3 + m3], xv[i], acc);
-    put(m3, acc * wv);
+          for (int i = 0; i < 7; ++i)
+            if (i < s.d1) acc = fmaf(mp[i * d3 + m3], xv[p][i], acc);
+          q[m3 * row_stride] = acc * w[p];
+        }
+      }
+    }
   }
-}
+};
 
-// rows kernel: A tile rows are (edge_local, m3), k = slab channel -> As[u][el*d3+m3]
-template <int SA>
-__device__ __forceinline__ void fill_dtp_rows(float* __restrict__ As, const DtpA& D, int e0, int ecnt, int slab) {
-  const int u = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const DtpSlab s = D.slabs[slab];
-  for (int el = g; el < ecnt; el += 8) {
-    float* q = As + u * SA + el * D.d3;
-    dtp_generate(D, s, (long)(e0 + el), u, [&](int m3, float v) { q[m3] = v; });
-  }
-}
-
-// tn kernel: reduction rows are (edge_local, m3), the M index is the DTP channel -> As[el*d3+m3][sl*32+u]
-template <int BM, int SA>
-__device__ __forceinline__ void fill_dtp_tn(float* __restrict__ As, const DtpA& D, int e0, int ecnt, int slab0,
-                                            int nslab) {
-  const int u = threadIdx.x & 31, g = threadIdx.x >> 5;
-  constexpr int SL = BM / 32;
-  // zero first (rows of invalid edges / padding rows must not inject NaNs into the reduction)
-  for (int i = threadIdx.x; i < BK * SA; i += NTHREADS) As[i] = 0.f;
-  __syncthreads();
-  for (int item = g; item < ecnt * SL; item += 8) {
-    const int el = item / SL, sl = item - el * SL;
-    if (sl >= nslab) continue;
-    const DtpSlab s = D.slabs[slab0 + sl];
-    float* q = As + (el * D.d3) * SA + sl * 32 + u;
-    dtp_generate(D, s, (long)(e0 + el), u, [&](int m3, float v) { q[m3 * SA] = v; });
+__device__ __forceinline__ void stage_coupling(float* __restrict__ Mt, const DtpA& D, int e0, int ecnt) {
+  const int n = ecnt * D.m_len;
+  for (int i = threadIdx.x; i < n; i += NTHREADS) {
+    const int el = i / D.m_len, j = i - el * D.m_len;
+    Mt[i] = D.coupling[(long)(e0 + el) * D.m_ld + D.m_base + j];
   }
 }
 
@@ -165,7 +199,7 @@ __device__ __forceinline__ void mma_step(const float* __restrict__ As, const flo
                                          int kbeg, int kend, f32x16 (&acc)[TM][TN]) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hi = lane >> 5;
-#pragma unroll 4
+#pragma unroll 8
   for (int kk = kbeg; kk < kend; kk += 2) {
     float a[TM], b[TN];
 #pragma unroll
@@ -203,10 +237,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
   constexpr int SB = (BMODE == B_KN) ? BN + 4 : BN + 1;
   __shared__ __attribute__((aligned(16))) float As[BK * SA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
+  __shared__ __attribute__((aligned(16))) float Mt[(AMODE == A_DTP) ? MAX_MTILE : 4];
 
   const int m0 = blockIdx.x * g.rows_per_tile;
   const int n0 = blockIdx.y * BN;
   const int mcnt = min(g.rows_per_tile, g.M - m0);
+  const int ncnt = min(BN, g.N - n0);
   const int wave = threadIdx.x >> 6;
   const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
 
@@ -218,22 +254,46 @@ __global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+  LoaderContigK<BM, SA> la;
+  LoaderDtp<ROWS_PAIRS> ld;
+  LoaderNatural<BN, SB> lbn;
+  LoaderContigK<BN, SB> lbk;
   int e0 = 0, ecnt = 0;
   if (AMODE == A_DTP) {
     e0 = blockIdx.x * g.dtp.ept;
     ecnt = mcnt / g.dtp.d3;
+    stage_coupling(Mt, g.dtp, e0, ecnt);
+    ld.issue(g.dtp, 0, e0, ecnt);
+  } else {
+    la.issue(g.A, m0, mcnt, 0, g.K, g.vecA);
   }
+  if (BMODE == B_KN)
+    lbn.issue(g.B, 0, min(BK, g.K), n0, g.N, g.vecB);
+  else
+    lbk.issue(g.B, n0, ncnt, 0, g.K, g.vecB);
+  if (AMODE == A_DTP) __syncthreads();  // coupling tile visible
 
   for (int k0 = 0; k0 < g.K; k0 += BK) {
-    if (AMODE == A_MEM)
-      fill_contigk<BM, SA>(As, g.A, m0, mcnt, k0, g.K, g.vecA);
+    if (AMODE == A_DTP)
+      ld.commit(As, Mt, g.dtp.m_len, g.dtp.d3, ecnt, 1, SA, 0);
     else
-      fill_dtp_rows<SA>(As, g.dtp, e0, ecnt, k0 / BK);
+      la.commit(As);
     if (BMODE == B_KN)
-      fill_natural<BN, SB>(Bs, g.B, k0, min(BK, g.K - k0), n0, g.N, g.vecB);
+      lbn.commit(Bs);
     else
-      fill_contigk<BN, SB>(Bs, g.B, n0, min(BN, g.N - n0), k0, g.K, g.vecB);
+      lbk.commit(Bs);
     __syncthreads();
+    const int k1 = k0 + BK;
+    if (k1 < g.K) {
+      if (AMODE == A_DTP)
+        ld.issue(g.dtp, k1 / BK, e0, ecnt);
+      else
+        la.issue(g.A, m0, mcnt, k1, g.K, g.vecA);
+      if (BMODE == B_KN)
+        lbn.issue(g.B, k1, min(BK, g.K - k1), n0, g.N, g.vecB);
+      else
+        lbk.issue(g.B, n0, ncnt, k1, g.K, g.vecB);
+    }
     mma_step<TM, TN, SA, SB>(As, Bs, wm0, wn0, 0, BK, acc);
     __syncthreads();
   }
@@ -279,6 +339,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN * WK == 4 && TM >= 1 && TN >= 1, "4 waves");
   constexpr int SA = BM + 4, SB = BN + 4;
+  constexpr int SL = BM / 32;
   __shared__ __attribute__((aligned(16))) float As[BK * SA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
 
@@ -301,15 +362,51 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
   const int s_end = min(total_steps, s_beg + g.steps_per_split);
   const int nslab = min(BM, g.M - m0) / 32;
 
+  LoaderNatural<BM, SA> la;
+  LoaderDtp<TN_PAIRS> ld[SL];
+  LoaderNatural<BN, SB> lb;
+
+  // in DTP mode the (tiny) coupling rows are read straight from global memory (L1 resident, lane-uniform)
+  auto issue = [&](int s) {
+    const int r0 = s * g.rows_per_step;
+    const int rcnt = min(g.rows_per_step, g.R - r0);
+    if (AMODE == A_MEM) {
+      la.issue(g.A, r0, rcnt, m0, g.M, g.vecA);
+    } else {
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl)
+        if (sl < nslab) ld[sl].issue(g.dtp, m0 / 32 + sl, s * g.dtp.ept, rcnt / g.dtp.d3);
+    }
+    lb.issue(g.B, r0, rcnt, n0, g.N, g.vecB);
+  };
+
+  if (AMODE == A_DTP) {
+    for (int i = threadIdx.x; i < BK * SA; i += NTHREADS) As[i] = 0.f;  // padding rows / absent slabs stay zero
+    __syncthreads();
+  }
+  if (s_beg < s_end) issue(s_beg);
   for (int s = s_beg; s < s_end; ++s) {
     const int r0 = s * g.rows_per_step;
     const int rcnt = min(g.rows_per_step, g.R - r0);
-    if (AMODE == A_MEM)
-      fill_natural<BM, SA>(As, g.A, r0, rcnt, m0, g.M, g.vecA);
-    else
-      fill_dtp_tn<BM, SA>(As, g.dtp, s * g.dtp.ept, rcnt / g.dtp.d3, m0 / 32, nslab);
-    fill_natural<BN, SB>(Bs, g.B, r0, rcnt, n0, g.N, g.vecB);
+    if (AMODE == A_MEM) {
+      la.commit(As);
+    } else {
+      const int ecnt = rcnt / g.dtp.d3;
+      const float* Mg = g.dtp.coupling + (long)(s * g.dtp.ept) * g.dtp.m_ld + g.dtp.m_base;
+      // rows of edges that are not part of this (last, partial) step must be zero
+      if (ecnt < g.dtp.ept) {
+        for (int i = threadIdx.x; i < (g.dtp.ept - ecnt) * g.dtp.d3 * BM; i += NTHREADS) {
+          const int rr = ecnt * g.dtp.d3 + i / BM, cc = i % BM;
+          As[rr * SA + cc] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl)
+        if (sl < nslab) ld[sl].commit(As, Mg, g.dtp.m_ld, g.dtp.d3, ecnt, SA, 1, sl * 32);
+    }
+    lb.commit(Bs);
     __syncthreads();
+    if (s + 1 < s_end) issue(s + 1);
     mma_step<TM, TN, SA, SB>(As, Bs, wm0, wn0, wk * (BK / WK), (wk + 1) * (BK / WK), acc);
     __syncthreads();
   }
@@ -338,28 +435,49 @@ inline bool rows_vec_ok(const float* base, const eqf_rows& r) {
   return aligned16(base) && (r.ld % 4 == 0) && (r.inner % 4 == 0);
 }
 
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+void launch_rows_cfg(const RowsArgs& a, hipStream_t st) {
+  dim3 grid(eqf_cdiv(a.M, a.rows_per_tile), eqf_cdiv(a.N, BN));
+  hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, WM, WN, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
+}
+
 template <int AMODE, int BMODE>
 int launch_rows(RowsArgs& a, hipStream_t st) {
-  const int mt = eqf_cdiv(a.M, a.rows_per_tile);
   if (a.M <= 0 || a.N <= 0) return 0;
   const int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+  // 64-row tiles when 128-row tiles would leave most of the 256 CUs without a workgroup
+  const int d = AMODE == A_DTP ? a.dtp.d3 : 1;
+  const long tiles128 = (long)eqf_cdiv(a.M, (128 / d) * d) * eqf_cdiv(a.N, bn);
+  int bm = (bn >= 64 && tiles128 < 1024) ? 64 : 128;
+  if (AMODE == A_DTP) {
+    if (bn >= 64 && ((128 / d) > 8 * ROWS_PAIRS || (128 / d) * a.dtp.m_len > MAX_MTILE)) bm = 64;
+    a.dtp.ept = bm / d;
+    a.rows_per_tile = a.dtp.ept * d;
+    if (a.dtp.ept > 8 * ROWS_PAIRS || a.dtp.ept * a.dtp.m_len > MAX_MTILE) return EQF_E_UNSUPPORTED;
+  } else {
+    a.rows_per_tile = bm;
+  }
   char name[96];
-  snprintf(name, sizeof name, "gemm_rows_128x%d_%s_%s", bn, AMODE == A_DTP ? "dtp" : "mem", BMODE == B_KN ? "kn" : "nk");
+  snprintf(name, sizeof name, "gemm_rows_%dx%d_%s_%s", bm, bn, AMODE == A_DTP ? "dtp" : "mem",
+           BMODE == B_KN ? "kn" : "nk");
   // algorithmic bytes: A (or the DTP inputs x,w,coupling) + B + C, each once
   const double a_bytes = AMODE == A_DTP
                              ? 4.0 * (double)(a.M / a.dtp.d3) * (a.dtp.x_ld + (a.dtp.w ? a.dtp.w_ld : 0) + a.dtp.m_ld)
                              : 4.0 * (double)a.M * a.K;
   const int pid = eqf_prof_begin(name, st, 2.0 * a.M * (double)a.N * a.K,
                                  a_bytes + 4.0 * (double)a.K * a.N + 4.0 * (double)a.M * a.N);
-  if (bn == 128) {
-    dim3 grid(mt, eqf_cdiv(a.N, 128));
-    hipLaunchKernelGGL((gemm_rows_kernel<128, 128, 2, 2, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
-  } else if (bn == 64) {
-    dim3 grid(mt, 1);
-    hipLaunchKernelGGL((gemm_rows_kernel<128, 64, 2, 2, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
+  if (bm == 128) {
+    if (bn == 128)
+      launch_rows_cfg<128, 128, 2, 2, AMODE, BMODE>(a, st);
+    else if (bn == 64)
+      launch_rows_cfg<128, 64, 2, 2, AMODE, BMODE>(a, st);
+    else
+      launch_rows_cfg<128, 32, 4, 1, AMODE, BMODE>(a, st);
   } else {
-    dim3 grid(mt, 1);
-    hipLaunchKernelGGL((gemm_rows_kernel<128, 32, 4, 1, AMODE, BMODE>), grid, dim3(NTHREADS), 0, st, a);
+    if (bn == 128)
+      launch_rows_cfg<64, 128, 2, 2, AMODE, BMODE>(a, st);
+    else
+      launch_rows_cfg<64, 64, 2, 2, AMODE, BMODE>(a, st);
   }
   eqf_prof_end(pid, st);
   EQF_CHECK_LAUNCH();
@@ -403,8 +521,9 @@ int launch_tn(TnArgs& a, hipStream_t st) {
 }
 
 // Build the per-slab table of output degree l3; returns K (channels of that degree) or <0 on error.
-int build_dtp(const eqf_dtp_paths* P, int l3, const float* x, const float* coupling, const float* w, DtpA& D,
-              int* out_off) {
+// The coupling row is laid out degree-major (layout.DtpTable), so the matrices of all paths that feed l3 form one
+// contiguous block [m_base, m_base + m_len).
+int build_dtp(const eqf_dtp_paths* P, int l3, const float* x, const float* coupling, const float* w, DtpA& D) {
   D.x = x;
   D.coupling = coupling;
   D.w = w;
@@ -412,29 +531,35 @@ int build_dtp(const eqf_dtp_paths* P, int l3, const float* x, const float* coupl
   D.m_ld = P->m_numel;
   D.w_ld = P->w_numel;
   D.d3 = 2 * l3 + 1;
-  int K = 0;
-  *out_off = -1;
+  int K = 0, m_lo = 1 << 30, m_hi = 0;
   for (int p = 0; p < P->npaths; ++p)
     if (P->l3[p] == l3) {
       K = P->out_k[p];
-      *out_off = P->out_off[p];
+      const int len = (2 * P->l1[p] + 1) * (2 * l3 + 1);
+      if (P->m_off[p] < m_lo) m_lo = P->m_off[p];
+      if (P->m_off[p] + len > m_hi) m_hi = P->m_off[p] + len;
     }
   if (K == 0) return 0;
   if (K % 32 != 0 || K / 32 > MAX_SLABS) return EQF_E_UNSUPPORTED;
+  D.m_base = m_lo;
+  D.m_len = m_hi - m_lo;
+  int m_sum = 0;
   for (int s = 0; s < K / 32; ++s) D.slabs[s].d1 = 0;
   for (int p = 0; p < P->npaths; ++p) {
     if (P->l3[p] != l3) continue;
     if (P->mul[p] % 32 != 0 || P->out_ch[p] % 32 != 0) return EQF_E_UNSUPPORTED;
     if (P->l1[p] > 3) return EQF_E_UNSUPPORTED;
+    m_sum += (2 * P->l1[p] + 1) * (2 * l3 + 1);
     for (int c = 0; c < P->mul[p]; c += 32) {
       DtpSlab& s = D.slabs[(P->out_ch[p] + c) / 32];
       s.d1 = 2 * P->l1[p] + 1;
       s.x_off = P->in_off[p] + c;
       s.x_mul = P->mul[p];
       s.w_off = P->w_off[p] + c;
-      s.m_off = P->m_off[p];
+      s.m_off = P->m_off[p] - m_lo;
     }
   }
+  if (m_sum != D.m_len) return EQF_E_BADARG;  // coupling row not degree-major
   for (int s = 0; s < K / 32; ++s)
     if (D.slabs[s].d1 == 0) return EQF_E_BADARG;
   return K;
@@ -452,7 +577,7 @@ int eqf_gemm_nn(const float* A, eqf_rows ra, const float* B, int ldb, float* C, 
   a.B = {B, 1, ldb, 0};
   a.C = {C, rc.d, rc.ld, rc.inner};
   a.bias = bias;
-  a.M = M, a.N = N, a.K = K, a.rows_per_tile = 128, a.accumulate = accumulate;
+  a.M = M, a.N = N, a.K = K, a.accumulate = accumulate;
   a.vecA = rows_vec_ok(A, ra);
   a.vecB = aligned16(B) && ldb % 4 == 0;
   return launch_rows<A_MEM, B_KN>(a, (hipStream_t)stream);
@@ -466,7 +591,7 @@ int eqf_gemm_nt(const float* A, eqf_rows ra, const float* B, int ldb, float* C, 
   a.B = {B, 1, ldb, 0};
   a.C = {C, rc.d, rc.ld, rc.inner};
   a.bias = bias;
-  a.M = M, a.N = N, a.K = K, a.rows_per_tile = 128, a.accumulate = accumulate;
+  a.M = M, a.N = N, a.K = K, a.accumulate = accumulate;
   a.vecA = rows_vec_ok(A, ra);
   a.vecB = aligned16(B) && ldb % 4 == 0;
   return launch_rows<A_MEM, B_NK>(a, (hipStream_t)stream);
@@ -494,15 +619,13 @@ int eqf_dtp_linear_fwd(const float* x, const float* coupling, const float* w, co
   for (int s = 0; s < out_irreps->nseg; ++s) {
     const int l3 = out_irreps->l[s], N = out_irreps->mul[s], d3 = 2 * l3 + 1;
     RowsArgs a{};
-    int dtp_off;
-    const int K = build_dtp(paths, l3, x, coupling, w, a.dtp, &dtp_off);
+    const int K = build_dtp(paths, l3, x, coupling, w, a.dtp);
     if (K < 0) return K;
     if (K == 0) return EQF_E_BADARG;  // an output degree nothing feeds
-    a.dtp.ept = 128 / d3;
     a.B = {Wl[l3], 1, N, 0};
     a.C = {out + off, d3, Dout, N};
     a.bias = (l3 == 0) ? bias0 : nullptr;
-    a.M = E * d3, a.N = N, a.K = K, a.rows_per_tile = a.dtp.ept * d3, a.accumulate = 0;
+    a.M = E * d3, a.N = N, a.K = K, a.accumulate = 0;
     a.vecA = 0;
     a.vecB = aligned16(Wl[l3]) && N % 4 == 0;
     int rc = launch_rows<A_DTP, B_KN>(a, (hipStream_t)stream);
@@ -520,8 +643,7 @@ int eqf_dtp_linear_wgrad(const float* x, const float* coupling, const float* w, 
   for (int s = 0; s < out_irreps->nseg; ++s) {
     const int l3 = out_irreps->l[s], N = out_irreps->mul[s], d3 = 2 * l3 + 1;
     TnArgs a{};
-    int dtp_off;
-    const int K = build_dtp(paths, l3, x, coupling, w, a.dtp, &dtp_off);
+    const int K = build_dtp(paths, l3, x, coupling, w, a.dtp);
     if (K < 0) return K;
     if (K == 0) return EQF_E_BADARG;
     a.dtp.ept = BK / d3;

@@ -337,14 +337,21 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------- column sum
+// 256 threads = 64 columns x 4 row lanes; each block reduces RCH rows of a 64-column strip, then one atomic per column
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int d, int ld, int inner, int R, int N,
-                                                     float* __restrict__ out, int CH) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  const int r0 = blockIdx.y * CH, r1 = min(R, r0 + CH);
+                                                     float* __restrict__ out, int RCH) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * RCH, r1 = min(R, r0 + RCH);
   float acc = 0.f;
-  for (int r = r0; r < r1; ++r) acc += X[row_off2(r, d, ld, inner) + c];
-  atomicAdd(out + c, acc);
+  if (c < N) {
+#pragma unroll 8
+    for (int r = r0 + rl; r < r1; r += 4) acc += X[row_off2(r, d, ld, inner) + c];
+  }
+  __shared__ float red[4][64];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < N) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
 }  // namespace
@@ -474,9 +481,9 @@ int eqf_embed_bwd(const int* type, const float* dy, float* dW, float* db, int ro
 int eqf_colsum(const float* X, eqf_rows rx, int R, int N, float* out, void* stream) {
   if (!X || !out || rx.d < 1) return EQF_E_BADARG;
   if (R <= 0 || N <= 0) return 0;
-  int CH = 256;
-  hipLaunchKernelGGL(colsum_kernel, dim3(eqf_cdiv(N, 256), eqf_cdiv(R, CH)), dim3(256), 0, (hipStream_t)stream, X, rx.d,
-                     rx.ld, rx.inner, R, N, out, CH);
+  const int RCH = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3(eqf_cdiv(N, 64), eqf_cdiv(R, RCH)), dim3(256), 0, (hipStream_t)stream, X, rx.d,
+                     rx.ld, rx.inner, R, N, out, RCH);
   EQF_CHECK_LAUNCH();
   return 0;
 }

@@ -95,16 +95,22 @@ class DtpTable:
         # instruction list in the unsimplified, sorted form (what e3nn / the reference's state_dict sees)
         self.irreps_out_unsimplified = Irreps(
             [(p["mul"], Irrep(p["l3"], 1)) for p in sorted(paths, key=lambda q: (q["l3"], paths.index(q)))])
-        cg_chunks, cg_off, m_off = [], 0, 0
+        cg_chunks, cg_off = [], 0
         for p in paths:
             i = self.layout_out.seg_index(p["l3"])
             p["out_off"] = self.layout_out.offsets[i]
             p["out_k"] = out_k[p["l3"]]
             t = so3.path_table(p["l1"], p["l2"], p["l3"]).astype(np.float32).reshape(-1)
-            p["cg_off"], p["m_off"] = cg_off, m_off
+            p["cg_off"] = cg_off
             cg_chunks.append(t)
             cg_off += t.size
-            m_off += (2 * p["l1"] + 1) * (2 * p["l3"] + 1)
+        # coupling row: degree-major (all matrices of the paths feeding l3 are contiguous), creation order inside
+        m_off = 0
+        for l3 in sorted(out_k):
+            for p in paths:
+                if p["l3"] == l3:
+                    p["m_off"] = m_off
+                    m_off += (2 * p["l1"] + 1) * (2 * p["l3"] + 1)
         self.paths = paths
         self.m_numel = m_off
         self.cg_host = torch.from_numpy(np.concatenate(cg_chunks))
@@ -125,6 +131,8 @@ class DtpTable:
         self._cg_dev = {}
         self.key = (repr(self.layout_in.irreps), self.lmax_sh, repr(self.irreps_out))
         self.fusable = all(p["mul"] % 32 == 0 for p in paths)
+        # every input segment is read by at least one path (then the backward writes all of dx)
+        self.in_covered = {p["in_off"] for p in paths} == set(self.layout_in.offsets)
 
     def cg(self, device):
         t = self._cg_dev.get(device)

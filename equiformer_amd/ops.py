@@ -50,6 +50,12 @@ def rows(d, ld, inner):
     return EqfRows(int(d), int(ld), int(inner))
 
 
+def _zeros2(n1, n2, device):
+    """Two zero-initialised fp32 accumulators carved out of ONE allocation (one fill kernel instead of two)."""
+    buf = torch.zeros(n1 + n2, device=device, dtype=torch.float32)
+    return buf[:n1], buf[n1:]
+
+
 # ------------------------------------------------------------------------------------------------- layer norm
 class _LayerNorm(Function):
     @staticmethod
@@ -74,8 +80,7 @@ class _LayerNorm(Function):
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(weight)
-        db = torch.zeros(ctx.nb, device=x.device, dtype=torch.float32)
+        dw, db = _zeros2(weight.numel(), ctx.nb, x.device)
         call("eqf_layernorm_bwd", _p(x), _p(weight), _p(dy), _p(rstd), _p(mean0), _p(dx), _p(dw), _p(db), x.shape[0],
              ctx.layout.c_ref, _stream())
         return dx, dw, db, None, None
@@ -149,14 +154,17 @@ class _IrrepsLinear(Function):
                 d = 2 * l + 1
                 call("eqf_gemm_nt", _p(dy, out_off), rows(d, Dout, N), _p(weight, w_off), N, _p(dx, in_off),
                      rows(d, Din, K), None, n * d, K, N, 0, st)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dw_, db_ = _zeros2(weight.numel(), spec.bias_dim if want_b else 0, x.device)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(weight)
+            dw = dw_
             for (l, in_off, K, out_off, N, w_off) in spec.pairs:
                 d = 2 * l + 1
                 call("eqf_gemm_tn", _p(x, in_off), rows(d, Din, K), _p(dy, out_off), rows(d, Dout, N), _p(dw, w_off), N,
                      K, N, n * d, st)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(spec.bias_dim, device=x.device, dtype=torch.float32)
+        if want_b:
+            db = db_
             j = spec.out_layout.seg_index(0)
             call("eqf_colsum", _p(dy, spec.out_layout.offsets[j]), rows(1, Dout, 0), n, spec.bias_dim, _p(db), st)
         return dx, dw, db, None
@@ -195,11 +203,14 @@ class _DenseLinear(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             call("eqf_gemm_nn", _p(dy), rows(1, N, 0), _p(weight), K, _p(dx), rows(1, K, 0), None, M, K, N, 0, st)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dw_, db_ = _zeros2(weight.numel(), N if want_b else 0, x.device)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(weight)
+            dw = dw_.view_as(weight)
             call("eqf_gemm_tn", _p(dy), rows(1, N, 0), _p(x), rows(1, K, 0), _p(dw), K, N, K, M, st)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(N, device=x.device, dtype=torch.float32)
+        if want_b:
+            db = db_
             call("eqf_colsum", _p(dy), rows(1, N, 0), M, N, _p(db), st)
         return dx, dw, db
 
@@ -284,8 +295,7 @@ class _LnSilu(Function):
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(beta)
+        dg, db = _zeros2(gamma.numel(), beta.numel(), x.device)
         call("eqf_lnsilu_bwd", _p(x), _p(gamma), _p(beta), _p(dy), _p(dx), _p(dg), _p(db), x.shape[0], x.shape[1],
              ctx.eps, _stream())
         return dx, dg, db, None
@@ -541,7 +551,7 @@ class _Dtp(Function):
         dout = _c(dout)
         _chk(dout)
         E = x.shape[0]
-        dx = torch.zeros_like(x)
+        dx = torch.empty_like(x) if ctx.table.in_covered else torch.zeros_like(x)
         dw = torch.empty_like(w) if (w is not None and ctx.needs_input_grad[2]) else None
         dM = torch.empty_like(coupling) if ctx.needs_input_grad[1] else None
         call("eqf_dtp_bwd", _p(x), _p(coupling), _p(w), ctx.table.c_ref, _p(dout), _p(dx), _p(dw), _p(dM), E, _stream())
@@ -614,20 +624,23 @@ class _DtpLinear(Function):
                 d = 2 * l3 + 1
                 call("eqf_gemm_nt", _p(dout, out_off), rows(d, Dout, N), _p(weight, w_off), N, _p(dmid, mid_off),
                      rows(d, Dmid, K), None, E * d, K, N, 0, st)
-            dx = torch.zeros_like(x)
+            dx = torch.empty_like(x) if table.in_covered else torch.zeros_like(x)
             dw = torch.empty_like(w) if (w is not None and ctx.needs_input_grad[2]) else None
             dM = torch.empty_like(coupling) if ctx.needs_input_grad[1] else None
             call("eqf_dtp_bwd", _p(x), _p(coupling), _p(w), table.c_ref, _p(dmid), _p(dx), _p(dw), _p(dM), E, st)
             del dmid
+        want_b = ctx.has_bias and ctx.needs_input_grad[4]
+        if ctx.needs_input_grad[3] or want_b:
+            dweight_, dbias_ = _zeros2(weight.numel(), spec.bias_dim if want_b else 0, x.device)
         if ctx.needs_input_grad[3]:
-            dweight = torch.zeros_like(weight)
+            dweight = dweight_
             dWl = (ctypes.c_void_p * 8)()
             for (l3, K, N, w_off, _, _) in spec.blocks:
                 dWl[l3] = dweight.data_ptr() + 4 * w_off
             call("eqf_dtp_linear_wgrad", _p(x), _p(coupling), _p(w), table.c_ref, _p(dout), spec.out_layout.c_ref, dWl,
                  E, st)
-        if ctx.has_bias and ctx.needs_input_grad[4]:
-            dbias = torch.zeros(spec.bias_dim, device=x.device, dtype=torch.float32)
+        if want_b:
+            dbias = dbias_
             j = spec.out_layout.seg_index(0)
             call("eqf_colsum", _p(dout, spec.out_layout.offsets[j]), rows(1, Dout, 0), E, spec.bias_dim, _p(dbias), st)
         return dx, dM, dw, dweight, dbias, None
