@@ -37,8 +37,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="molecules per GPU (reference script: 128)")
     ap.add_argument("--atoms", type=int, default=18)
     ap.add_argument("--side", type=float, default=6.5, help="cube edge of the synthetic molecules (6.5 -> ~200 edges)")
-    ap.add_argument("--dominant", default="gemm_rows_128x128_dtp_kn",
-                    help="kernel (name substring) timed with HIP events for the roofline line")
+    ap.add_argument("--dominant", default="",
+                    help="kernel-name substring timed with HIP events for the roofline line ('' = every matrix-core "
+                         "kernel; the one with the largest total time is reported)")
     ap.add_argument("--cpu-molecules", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=16)

@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures of tests/golden/ (run from the repo root:  python tests/golden/make_golden.py).
+
+What they pin.  The reference (atomicarchitects/equiformer) cannot be imported in this container (e3nn, PyG,
+torch_scatter, torch_cluster are absent and un-installable) and ships no golden vectors, so these fixtures are NOT
+outputs of the reference itself: they are outputs of the CPU oracle (oracle/, fp64) on fixed inputs and fixed weights
+(tests/golden/weights.py: numpy PCG64 stream, independent of torch's RNG).  They freeze the oracle (any later edit that changes its arithmetic fails tests/test_golden.py on
+CPU) and give the GPU tests a target that does not depend on torch's RNG stream.  Parity of the oracle with the
+reference stays "unpinned" in the sense of DESIGN.md; the conventions are pinned by the known-answer tests in
+tests/test_oracle_kat.py instead.
+
+Models are reduced copies of the BASELINE configs (2 blocks, 32-channel degrees, 64 scalar features) so that a fixture
+is a few kB; all code paths (radius graph, SH, RBF, radial MLP, DTP, gate, attention, layer norm, FFN with
+shortcut, head, pooling, MD17 forces, OC20 tag embedding + offsets) are exercised.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from equiformer_amd.synthetic import md17_aspirin_batch, qm9_like_batch  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from weights import fill_deterministic  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SMALL_L2 = dict(irreps_node_embedding="64x0e+32x1e+32x2e", num_layers=2, irreps_sh="1x0e+1x1e+1x2e",
+                fc_neurons=[64, 64], irreps_feature="64x0e", irreps_head="16x0e+8x1e+8x2e", num_heads=4,
+                nonlinear_message=True, irreps_mlp_mid="64x0e+32x1e+32x2e", alpha_drop=0.0)
+SMALL_L3 = dict(irreps_node_embedding="64x0e+32x1e+32x2e+32x3e", num_layers=2, irreps_sh="1x0e+1x1e+1x2e+1x3e",
+                fc_neurons=[64, 64], irreps_feature="64x0e", irreps_head="16x0e+8x1e+8x2e+8x3e", num_heads=4,
+                nonlinear_message=True, irreps_mlp_mid="64x0e+32x1e+32x2e+32x3e", alpha_drop=0.0)
+SMALL_OC20 = dict(irreps_node_embedding="64x0e+32x1e", num_layers=2, irreps_sh="1x0e+1x1e", max_radius=5.0,
+                  fc_neurons=[64, 64], irreps_feature="64x0e", irreps_head="16x0e+8x1e", num_heads=4,
+                  nonlinear_message=True, irreps_mlp_mid="128x0e+64x1e", alpha_drop=0.0)
+
+
+def _save(name, model, inputs, outputs):
+    arrs = {"in::" + k: np.asarray(v) for k, v in inputs.items()}
+    arrs.update({"out::" + k: np.asarray(v) for k, v in outputs.items()})
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(name, "%.0f kB" % (os.path.getsize(path) / 1e3), {k: np.asarray(v).shape for k, v in outputs.items()})
+
+
+def main():
+    torch.manual_seed(1234)
+    # ---- QM9-shaped (config #1/#2)
+    m = onets.GraphAttentionTransformer(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **SMALL_L2).eval()
+    fill_deterministic(m, 11)
+    d = qm9_like_batch(3, 12, side=5.5, seed=7)
+    md = m.double()
+    pos = d["pos"].double().requires_grad_(True)
+    y = md(None, pos, d["batch"], d["z"])
+    loss = (y.squeeze() - d["y"].double()).abs().mean()
+    grads = torch.autograd.grad(loss, [md.blocks[0].ga.sep_act.lin.tp.weight, md.blocks[1].ga.alpha_dot,
+                                       md.blocks[0].ga.sep_act.dtp_rad.net[0].weight, md.rbf.mean])
+    _save("qm9_small", m.float(), dict(pos=d["pos"].numpy(), z=d["z"].numpy(), batch=d["batch"].numpy(),
+                                      y=d["y"].numpy()),
+          dict(energy=y.detach().numpy(), loss=loss.item(), g_sep_act_lin=grads[0].numpy(),
+               g_alpha_dot=grads[1].numpy(), g_rad0=grads[2].numpy(), g_rbf_mean=grads[3].numpy()))
+
+    # ---- MD17-shaped, L_max = 2 and 3 (configs #3/#4): energy and forces
+    for tag, kw in (("md17_small_l2", SMALL_L2), ("md17_small_l3", SMALL_L3)):
+        m = onets.GraphAttentionTransformerMD17(irreps_in="64x0e", max_radius=5.0, number_of_basis=32,
+                                                basis_type="exp", **kw).eval()
+        fill_deterministic(m, 12)
+        d = md17_aspirin_batch(2, seed=3)
+        e, f = m.double()(d["z"], d["pos"].double(), d["batch"])
+        _save(tag, m.float(), dict(pos=d["pos"].numpy(), z=d["z"].numpy(), batch=d["batch"].numpy()),
+              dict(energy=e.detach().numpy(), forces=f.detach().numpy()))
+
+    # ---- OC20-shaped (config #5): explicit edges with Cartesian offsets, tags
+    m = onets.GraphAttentionTransformerOC20(number_of_basis=32, **SMALL_OC20).eval()
+    fill_deterministic(m, 13)
+    rng = np.random.default_rng(5)
+    n, B = 20, 2
+    cell = 7.0
+    pos = rng.uniform(0, cell, size=(B * n, 3)).astype(np.float32).astype(np.float64)
+    batch = np.repeat(np.arange(B), n)
+    z = rng.integers(1, 84, size=B * n)
+    tags = rng.integers(0, 3, size=B * n)
+    src, dst, off = [], [], []
+    shifts = [np.array([i, j, 0.0]) * cell for i in (-1, 0, 1) for j in (-1, 0, 1)]
+    for b in range(B):
+        for i in range(b * n, (b + 1) * n):
+            for j in range(b * n, (b + 1) * n):
+                for s in shifts:
+                    if i == j and not s.any():
+                        continue
+                    if np.linalg.norm(pos[j] + s - pos[i]) < 5.0:
+                        src.append(j), dst.append(i), off.append(s)
+    e = m.double()(torch.tensor(z), torch.tensor(tags), torch.tensor(pos), torch.tensor(batch),
+                   edge_index=torch.tensor(np.array([src, dst])), offsets=torch.tensor(np.array(off)))
+    _save("oc20_small", m.float(), dict(pos=pos.astype(np.float32), z=z, tags=tags, batch=batch,
+                                       edge_index=np.array([src, dst]), offsets=np.array(off, dtype=np.float32)),
+          dict(energy=e.detach().numpy()))
+
+
+if __name__ == "__main__":
+    main()
