@@ -59,6 +59,9 @@ SIGNATURES = {
     "eqf_dtp_coupling_bwd": [c_fp, c_fp, _P_PATHS, c_fp, c_int, c_fp],
     "eqf_dtp_linear_fwd": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, _P_IRR, c_int, c_fp],
     "eqf_dtp_linear_wgrad": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, _PP, c_int, c_fp],
+    "eqf_sfc_fwd": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, _P_IRR, c_fp, c_int, c_int, c_fp],
+    "eqf_sfc_bwd_data": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, _P_IRR, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp],
+    "eqf_sfc_bwd_weight": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, c_fp, c_int, _PP, c_int, c_fp],
     "eqf_layernorm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, _f, c_fp],
     "eqf_layernorm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, c_fp],
     "eqf_gate_fwd": [c_fp, c_fp, c_int, c_int, _P_IRR, _f, _f, c_fp],

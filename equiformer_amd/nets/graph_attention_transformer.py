@@ -108,10 +108,11 @@ class _Trunk(nn.Module):
         return set(no_wd_list)
 
     def set_fused(self, flag):
-        """Toggle the fused DTP->linear MFMA kernels (on by default); the un-fused path is their on-device check."""
+        """True (default): fused SeparableFCTP kernels (eqf_sfc_*); "legacy": the per-degree DTP-generating GEMMs
+        (eqf_dtp_linear_*); False: un-fused DTP + linear.  The slower paths are the on-device cross-checks."""
         for m in self.modules():
             if hasattr(m, "use_fused"):
-                m.use_fused = bool(flag)
+                m.use_fused = "legacy" if flag == "legacy" else bool(flag)
 
     def _trunk_forward(self, node_embedding, pos, graph, offsets=None):
         _, edge_length, edge_sh = ops.edge_geometry(pos, offsets, graph, self.lmax_sh)

@@ -310,6 +310,7 @@ class SeparableFCTP(nn.Module):
         self.norm = None
         self.gate = make_gate(self.irreps_node_output) if use_activation else None
         self.fused_spec = ops.DtpLinearSpec(self.dtp.table, self.lin.layout_out) if self.dtp.table.fusable else None
+        self.sfc_spec = ops.SfcSpec(self.dtp.table, self.lin.layout_out)
         if internal_weights:
             # row (path, channel) of the stacked lin weight -> index of its shared DTP weight
             idx = []
@@ -331,13 +332,28 @@ class SeparableFCTP(nn.Module):
             r += K
         return torch.cat(chunks)
 
+    def degree_weights(self):
+        """[K(l), N(l)] views of the flat lin weight, one per output degree (ascending); the shared depth-wise weights
+        (internal_weights=True) are folded into the rows."""
+        Ws, r = [], 0
+        scale = self.dtp.tp.weight[self._row_to_w] if self.dtp.tp.internal_weights else None
+        for (l, _, K, _, N, w_off) in self.lin.spec.pairs:
+            W = self.lin.tp.weight[w_off:w_off + K * N].view(K, N)
+            if scale is not None:
+                W = W * scale[r:r + K, None]
+            Ws.append(W)
+            r += K
+        return Ws
+
     def forward(self, node_input, ectx, use_fused=True):
         table = self.dtp.table
         M = ectx.coupling(table)
         internal = self.dtp.tp.internal_weights
         w = self.dtp_rad(ectx.edge_scalars) if self.dtp_rad is not None else None
         bias = self.lin._bias()
-        if use_fused and self.fused_spec is not None:
+        if use_fused is True and self.sfc_spec.supported:
+            out = ops.sep_fctp(node_input, M, w, bias, self.sfc_spec, self.degree_weights())
+        elif use_fused == "legacy" and self.fused_spec is not None:
             weight = self.folded_lin_weight() if internal else self.lin.tp.weight
             out = ops.dtp_linear(node_input, M, w, weight, bias, self.fused_spec)
         else:
@@ -386,6 +402,8 @@ class GraphAttention(nn.Module):
                                        use_activation=False, norm_layer=None, internal_weights=True)
         self.alpha_fused_spec = (ops.DtpLinearSpec(self.sep_act.dtp.table, self.sep_alpha.layout_out)
                                  if self.sep_act.dtp.table.fusable else None)
+        # value linear + attention-logit linear share ONE generation of the DTP output (concatenated degree-0 weight)
+        self.act_sfc_spec = ops.SfcSpec(self.sep_act.dtp.table, self.sep_act.lin.layout_out, n2=mul_alpha)
         self.heads_layout = RowLayout(irreps_attn_heads)
 
         self.alpha_dot = nn.Parameter(torch.randn(1, num_heads, self.mul_alpha_head))
@@ -405,7 +423,13 @@ class GraphAttention(nn.Module):
         table = sa.dtp.table
         M = ectx.coupling(table)
         weight = sa.dtp_rad(ectx.edge_scalars)
-        if self.use_fused and sa.fused_spec is not None:
+        if self.use_fused is True and self.act_sfc_spec.supported:
+            Ws = sa.degree_weights()
+            K0 = Ws[0].shape[0]
+            Ws[0] = torch.cat([Ws[0], self.sep_alpha.tp.weight.view(K0, -1)], dim=1)
+            bias = torch.cat([sa.lin._bias(), self.sep_alpha._bias()])
+            value, alpha = ops.sep_fctp(message, M, weight, bias, self.act_sfc_spec, Ws)
+        elif self.use_fused and sa.fused_spec is not None:
             value = ops.dtp_linear(message, M, weight, sa.lin.tp.weight, sa.lin._bias(), sa.fused_spec)
             alpha = ops.dtp_linear(message, M, weight, self.sep_alpha.tp.weight, self.sep_alpha._bias(),
                                    self.alpha_fused_spec)
@@ -519,6 +543,7 @@ class EdgeDegreeEmbeddingNetwork(nn.Module):
         self.proj = LinearRS(self.dw.table.irreps_out, irreps_node_embedding)
         self.scale_scatter = ScaledScatter(avg_aggregate_num)
         self.fused_spec = ops.DtpLinearSpec(self.dw.table, self.proj.layout_out) if self.dw.table.fusable else None
+        self.sfc_spec = ops.SfcSpec(self.dw.table, self.proj.layout_out)
         self.D = self.exp.layout_out.dim
         self.C = self.exp.layout_out.mul_of(0)
         self.use_fused = True
@@ -531,7 +556,10 @@ class EdgeDegreeEmbeddingNetwork(nn.Module):
         weight = self.rad(ectx.edge_scalars)
         src_features = ops.gather_add(node_features, None, g)
         M = ectx.coupling(self.dw.table)
-        if self.use_fused and self.fused_spec is not None:
+        if self.use_fused is True and self.sfc_spec.supported:
+            Ws = [self.proj.tp.weight[w_off:w_off + K * N].view(K, N) for (_, _, K, _, N, w_off) in self.proj.spec.pairs]
+            edge_features = ops.sep_fctp(src_features, M, weight, self.proj._bias(), self.sfc_spec, Ws)
+        elif self.use_fused and self.fused_spec is not None:
             edge_features = ops.dtp_linear(src_features, M, weight, self.proj.tp.weight, self.proj._bias(),
                                            self.fused_spec)
         else:

@@ -650,6 +650,118 @@ def dtp_linear(x, coupling, w, weight, bias, spec):
     return _DtpLinear.apply(x, coupling, w, weight, bias, spec)
 
 
+# ------------------------------------------------------------------------------------------------- fused SeparableFCTP
+class SfcSpec:
+    """Fused DTP -> per-degree linear(s) (eqf_sfc_*): `out_layout` = irreps of the main consumer (one [K(l), N1(l)]
+    weight per degree), `n2` = width of an optional second scalar consumer fed by the degree-0 DTP output (its weight
+    is concatenated to the degree-0 matrix: [K(0), N1(0)+n2])."""
+
+    def __init__(self, table, out_layout, n2=0):
+        self.table, self.out_layout, self.n2 = table, out_layout, int(n2)
+        self.degs = []  # (l3, K, N1, Ncat)
+        ok = table.fusable
+        for (N1, l3) in out_layout.segs:
+            i = table.layout_out.seg_index(l3)
+            if i is None:
+                raise NotImplementedError("output degree %d is not produced by the tensor product" % l3)
+            K = table.layout_out.segs[i][0]
+            ncat = N1 + (self.n2 if l3 == 0 else 0)
+            ok = ok and ncat % 32 == 0 and N1 % 4 == 0 and l3 <= 3
+            self.degs.append((l3, K, N1, ncat))
+        if self.n2 and out_layout.seg_index(0) is None:
+            ok = False
+        self.supported = ok and len(self.degs) <= 4
+        self.bias_dim = out_layout.mul_of(0) + self.n2
+        used = {l3 for l3, _, _, _ in self.degs}
+        self.in_covered = {p["in_off"] for p in table.paths if p["l3"] in used} == set(table.layout_in.offsets)
+
+
+def _ptr_array(pairs):
+    arr = (ctypes.c_void_p * 8)()
+    for l3, t in pairs:
+        arr[l3] = t.data_ptr()
+    return arr
+
+
+class _SepFctp(Function):
+    @staticmethod
+    def forward(ctx, x, coupling, w, bias, spec, *Ws):
+        x, coupling = _c(x), _c(coupling)
+        w = _c(w) if w is not None else None
+        Ws = tuple(_c(W) for W in Ws)
+        _chk(x, coupling, w, bias, *Ws)
+        E = x.shape[0]
+        assert len(Ws) == len(spec.degs)
+        for (l3, K, N1, ncat), W in zip(spec.degs, Ws):
+            assert tuple(W.shape) == (K, ncat), (tuple(W.shape), K, ncat)
+        out1 = torch.empty((E, spec.out_layout.dim), device=x.device, dtype=torch.float32)
+        out2 = torch.empty((E, spec.n2), device=x.device, dtype=torch.float32) if spec.n2 else None
+        Wl = _ptr_array((d[0], W) for d, W in zip(spec.degs, Ws))
+        call("eqf_sfc_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(bias), _p(out1),
+             spec.out_layout.c_ref, _p(out2), spec.n2, E, _stream())
+        ctx.save_for_backward(x, coupling, w, *Ws)
+        ctx.spec = spec
+        ctx.has_bias = bias is not None
+        if out2 is None:
+            return out1
+        return out1, out2
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d1, d2=None):
+        x, coupling, w, *Ws = ctx.saved_tensors
+        spec = ctx.spec
+        E = x.shape[0]
+        st = _stream()
+        dev = x.device
+        if d1 is None:
+            d1 = torch.zeros((E, spec.out_layout.dim), device=dev, dtype=torch.float32)
+        if spec.n2 and d2 is None:
+            d2 = torch.zeros((E, spec.n2), device=dev, dtype=torch.float32)
+        d1 = _c(d1)
+        d2 = _c(d2) if spec.n2 else None
+        _chk(d1, d2)
+        nW = len(Ws)
+        need = ctx.needs_input_grad
+        dx = dM = dw = dbias = None
+        if need[0] or need[1] or (w is not None and need[2]):
+            dx = (torch.empty_like if spec.in_covered else torch.zeros_like)(x)
+            dw = torch.empty_like(w) if w is not None else None
+            dM = torch.zeros_like(coupling) if need[1] else None
+            Wl = _ptr_array((d[0], W) for d, W in zip(spec.degs, Ws))
+            call("eqf_sfc_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(d1), spec.out_layout.c_ref,
+                 _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, st)
+        dWs = [None] * nW
+        want_b = ctx.has_bias and need[3]
+        if any(need[5:5 + nW]) or want_b:
+            sizes = [W.numel() for W in Ws]
+            flat = torch.zeros(sum(sizes) + (spec.bias_dim if want_b else 0), device=dev, dtype=torch.float32)
+            off = 0
+            for i, (W, n) in enumerate(zip(Ws, sizes)):
+                dWs[i] = flat[off:off + n].view_as(W)
+                off += n
+            if any(need[5:5 + nW]):
+                dWl = _ptr_array((d[0], g) for d, g in zip(spec.degs, dWs))
+                call("eqf_sfc_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref,
+                     _p(d2), spec.n2, dWl, E, st)
+            if want_b:
+                dbias = flat[off:off + spec.bias_dim]
+                j = spec.out_layout.seg_index(0)
+                n1 = spec.out_layout.segs[j][0] if j is not None else 0
+                if n1:
+                    call("eqf_colsum", _p(d1, spec.out_layout.offsets[j]), rows(1, spec.out_layout.dim, 0), E, n1,
+                         _p(dbias), st)
+                if spec.n2:
+                    call("eqf_colsum", _p(d2), rows(1, spec.n2, 0), E, spec.n2, _p(dbias, n1), st)
+        return (dx, dM, dw, dbias, None) + tuple(dWs)
+
+
+def sep_fctp(x, coupling, w, bias, spec, Ws):
+    """Fused DTP -> linear(s).  Ws: one [K(l3), N1(l3) (+ n2 for l3 == 0)] tensor per degree of spec.out_layout.
+    Returns out1 (and out2 when spec.n2 > 0)."""
+    return _SepFctp.apply(x, coupling, w, bias, spec, *Ws)
+
+
 # ------------------------------------------------------------------------------------------------- attention
 class _AlphaLogits(Function):
     @staticmethod

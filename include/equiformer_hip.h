@@ -164,6 +164,29 @@ int eqf_dtp_linear_wgrad(const float* x, const float* coupling, const float* w,
                          const eqf_dtp_paths* paths, const float* d_out,
                          const eqf_irreps* out_irreps, float* const* dWl, int E, void* stream);
 
+/* Fused SeparableFCTP (the edge hot loop): depth-wise tensor product -> per-degree linear for ALL output degrees and
+ * ALL consumers of the DTP output in one launch; the DTP result is never written to memory in either direction.
+ *   out1[e, seg(l3)]  = DTP(x, sh, w)[e, seg(l3)] . Wl[l3][:, 0:N1(l3)]                 for every degree of out1_irreps
+ *   out2[e, 0:n2]     = DTP(x, sh, w)[e, seg(0)]  . Wl[0][:, N1(0):N1(0)+n2]            (optional second scalar consumer)
+ * Wl[l3]: device pointers (HOST array indexed by l3) to row-major [K(l3), N1(l3) + (l3 == 0 ? n2 : 0)] matrices, K(l3) =
+ * channels of the DTP output of degree l3; bias0 (may be NULL) has N1(0)+n2 entries and is added to the degree-0
+ * columns.  out2 == NULL <=> n2 == 0.  w may be NULL (unit path weights).  Requires every path multiplicity and every
+ * N1(l3)+n2 to be a multiple of 32.
+ * [ref: SeparableFCTP.forward nets/graph_attention_transformer.py:234-248 (dtp + lin) together with sep_alpha :492;
+ *       EdgeDegreeEmbeddingNetwork.forward :725-733 (dw + proj)] */
+int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                const float* const* Wl, const float* bias0, float* out1, const eqf_irreps* out1_irreps, float* out2,
+                int n2, int E, void* stream);
+/* Data gradient of eqf_sfc_fwd: dx[E,in_dim] written; dw[E,w_numel] written if non-NULL (ignored when w == NULL);
+ * d_coupling[E,m_numel] (may be NULL; needed only when forces are differentiated) is ACCUMULATED with atomics. */
+int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                     const float* const* Wl, const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2,
+                     int n2, float* dx, float* dw, float* d_coupling, int E, void* stream);
+/* Weight gradient of eqf_sfc_fwd: dWl[l3] (same shapes as Wl[l3]) ACCUMULATED (fp32 atomics). */
+int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                       const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2, int n2,
+                       float* const* dWl, int E, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Row-local feature ops (nodes or edges)
  * ------------------------------------------------------------------------------------------- */

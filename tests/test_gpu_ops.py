@@ -363,7 +363,7 @@ def test_separable_fctp_fused_and_unfused(irr, sh_irr, use_act):
     es = torch.rand(E, 16, generator=g, dtype=torch.float64).requires_grad_(True)
     yr = ref(x, sh, es if use_act else None)
     go, gref = _grads(yr, [x, sh] + ([es] if use_act else []) + list(ref.parameters()))
-    for fused in (True, False):
+    for fused in (True, "legacy", False):
         xg = _cf(x.detach().float().to(dev), lay_in).requires_grad_(True)
         shg = sh.detach().float().to(dev).requires_grad_(True)
         esg = es.detach().float().to(dev).requires_grad_(True)
@@ -375,6 +375,48 @@ def test_separable_fctp_fused_and_unfused(irr, sh_irr, use_act):
         assert _rel(_e3(gout[0], lay_in), gref[0]) < 3e-5, fused
         for i, (a, r) in enumerate(zip(gout[1:], gref[1:])):
             assert _rel(a, r) < 5e-5, (fused, i)
+
+
+@pytest.mark.parametrize("irr,sh_irr,n2,E", [("128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", 128, 333),
+                                             ("128x0e+64x1e+64x2e+32x3e", "1x0e+1x1e+1x2e+1x3e", 128, 130),
+                                             ("256x0e+128x1e", "1x0e+1x1e", 256, 77),
+                                             ("64x0e+32x1e+32x2e", "1x0e+1x1e+1x2e", 64, 1)])
+def test_sfc_two_consumers_matches_unfused(irr, sh_irr, n2, E):
+    """eqf_sfc_* with the second scalar consumer (attention logits) against the un-fused composition
+    DTP -> {per-degree linear, scalar linear}: outputs and every gradient (x, sh, w, weights, bias)."""
+    from equiformer_amd import ops
+    from equiformer_amd.layout import DtpTable, RowLayout
+    dev = _dev()
+    table = DtpTable(irr, sh_irr, irr)
+    lay_out = RowLayout(irr)
+    lay_mid = table.layout_out
+    lmax = len(oe3.Irreps(sh_irr)) - 1
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(E, table.layout_in.dim, generator=g).to(dev).requires_grad_(True)
+    sh = oe3.spherical_harmonics(lmax, torch.randn(E, 3, generator=g, dtype=torch.float64)).float().to(dev).requires_grad_(True)
+    w = torch.randn(E, table.weight_numel, generator=g).to(dev).requires_grad_(True)
+    spec = ops.SfcSpec(table, lay_out, n2=n2)
+    assert spec.supported
+    Ws = [(torch.randn(K, ncat, generator=g) / K ** 0.5).to(dev).requires_grad_(True) for (_, K, _, ncat) in spec.degs]
+    bias = torch.randn(spec.bias_dim, generator=g).to(dev).requires_grad_(True)
+    M = ops.dtp_coupling(sh, table)
+    o1, o2 = ops.sep_fctp(x, M, w, bias, spec, Ws)
+    # reference composition on the GPU from the un-fused primitives
+    mid = ops.dtp(x, ops.dtp_coupling(sh, table), w, table)
+    lin_spec = ops.LinearSpec(lay_mid, lay_out)
+    n1_0 = lay_out.mul_of(0)
+    flat = torch.cat([W[:, :N1].reshape(-1) for (_, _, N1, _), W in zip(spec.degs, Ws)])
+    r1 = ops.irreps_linear(mid, flat, bias[:n1_0], lin_spec)
+    K0 = spec.degs[0][1]
+    r2 = mid[:, :K0] @ Ws[0][:, n1_0:] + bias[n1_0:]
+    assert _rel(o1, r1) < 1e-5 and _rel(o2, r2) < 1e-5
+    g1 = torch.randn(o1.shape, generator=g).to(dev)
+    g2 = torch.randn(o2.shape, generator=g).to(dev)
+    ins = [x, sh, w, bias] + Ws
+    ga = torch.autograd.grad([o1, o2], ins, [g1, g2])
+    gb = torch.autograd.grad([r1, r2], ins, [g1, g2])
+    for i, (a, b) in enumerate(zip(ga, gb)):
+        assert _rel(a, b) < 3e-5, i
 
 
 # ------------------------------------------------------------------------------------------------- attention
