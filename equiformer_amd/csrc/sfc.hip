@@ -26,6 +26,9 @@
 #include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+extern __shared__ __attribute__((aligned(16))) float sfc_lds[];  // dynamic LDS of every kernel in this file
 
 namespace {
 
@@ -67,10 +70,25 @@ struct SfcCommon {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
+// These kernels are instruction-issue bound unless every small loop is unrolled with compile-time trip counts (the
+// first, runtime-indexed version spent 23 VALU + 10 SALU instructions per MFMA): the bodies are therefore templated
+// on the degrees (D1 = 2*l1+1 of the slab, D3 = 2*l3+1 of the output) and dispatched with wave-uniform switches, so
+// that all LDS offsets are immediates and no per-MFMA branches remain.
 constexpr int F_TE = 64;     // edges per tile
 constexpr int F_NP = 8;      // edges per generating thread
-constexpr int F_MAXT = 4;    // 32x32 accumulator tiles per wave
+constexpr int F_MAXT = 4;    // 32x32 accumulator tiles per wave (upper bound; FT<MAXD> below)
 constexpr int F_MAXCT = 6;   // column tiles per workgroup
+// column tiles a workgroup of output degree d3 can take with `ft` accumulator tiles per wave, and the row stride of
+// its staged weight tile
+__host__ __device__ constexpr int f_ctcap(int d3, int ft) {
+  return (4 * ft) / (F_TE * d3 / 32) < F_MAXCT ? (4 * ft) / (F_TE * d3 / 32) : F_MAXCT;
+}
+__host__ __device__ constexpr int f_sb(int d3, int ft) { return f_ctcap(d3, ft) * 32 + 4; }
+
+template <int N>
+struct IC {
+  static constexpr int value = N;
+};
 
 struct SfcFwdArgs {
   SfcCommon c;
@@ -78,26 +96,44 @@ struct SfcFwdArgs {
   int nsplit[SFC_MAX_DEG], cps[SFC_MAX_DEG], blk0[SFC_MAX_DEG + 1];
 };
 
-template <int MAXD>
-__global__ __launch_bounds__(256, 2) void sfc_fwd_kernel(const SfcFwdArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  int b = blockIdx.x, di = 0;
-  while (di + 1 < g.c.ndeg && b >= g.blk0[di + 1]) ++di;
-  b -= g.blk0[di];
+template <int D3, int NT, int FT>
+__device__ __forceinline__ void f_mma(const int (&aidx)[FT], const int (&bidx)[FT], f32x16 (&acc)[FT]) {
+  constexpr int SA = F_TE * D3 + 1, F_SB = f_sb(D3, FT);
+  int ai[NT], bi[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) ai[i] = aidx[i], bi[i] = bidx[i];
+#pragma unroll 1
+  for (int kq = 0; kq < 4; ++kq) {  // 4 x (4 k-pairs): bounded unrolling keeps the operand registers in check
+#pragma unroll
+    for (int kk = 0; kk < 8; kk += 2) {
+      float av[NT], bw[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        av[i] = sfc_lds[ai[i] + kk * SA];
+        bw[i] = sfc_lds[bi[i] + kk * F_SB];
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bw[i], acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) ai[i] += 8 * SA, bi[i] += 8 * F_SB;
+  }
+}
+
+template <int D3, int MAXD>
+__device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const int b) {
+  constexpr int ROWS = F_TE * D3, RT = ROWS / 32, SA = ROWS + 1;
+  constexpr int FT = (MAXD <= 5) ? 3 : F_MAXT;  // accumulator tiles per wave (host: `ft`)
+  constexpr int CTCAP = f_ctcap(D3, FT), F_SB = f_sb(D3, FT);
   const SfcDeg& D = g.c.deg[di];
   const int nsplit = g.nsplit[di];
   const int tile = b / nsplit, ns = b - tile * nsplit;
   const int e0 = tile * F_TE;
   const int ecnt = min(F_TE, g.c.E - e0);
-  const int d3 = D.d3;
-  const int rows = F_TE * d3, RT = rows >> 5;
   const int ncol0 = ns * g.cps[di];
   const int ncols = min(g.cps[di], D.Ncat - ncol0);
   const int CT = ncols >> 5;
-  const int SA = rows + 1, SB = ncols + 4;
-  float* __restrict__ As = smem;
-  float* __restrict__ Bs = As + 32 * SA;  // 32*SA floats: a multiple of 128 bytes
-  float* __restrict__ Mt = Bs + 32 * SB;
+  constexpr int AS0 = 0, BS0 = 32 * SA, MT0 = BS0 + 32 * F_SB;  // LDS partition (float offsets into sfc_lds)
   const int m_len = D.m_len;
 
   const int t = threadIdx.x;
@@ -105,75 +141,101 @@ __global__ __launch_bounds__(256, 2) void sfc_fwd_kernel(const SfcFwdArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = t & 63, r = lane & 31, hi = lane >> 5;
 
-  // tiles of this wave: tt = wave + 4 i  ->  (rt = tt % RT, ct = tt / RT); all of this is wave-uniform
+  // tiles of this wave: tt = wave + 4 i  ->  (rt = tt % RT, ct = tt / RT); all of it wave-uniform.  Every wave runs
+  // NT = ceil(ntile / 4) tiles per step (the barrier makes the slowest wave the pace anyway); surplus slots recompute
+  // tile `wave` into an accumulator that is never stored.
   const int ntile = RT * CT;
-  const int ntw = (ntile - wave + 3) >> 2;  // number of tiles of this wave
-  int aoff[F_MAXT], boff[F_MAXT];
-  f32x16 acc[F_MAXT];
+  const int NT = (ntile + 3) >> 2;
+  const int ntw = (ntile - wave + 3) >> 2;
+  int aoff[FT], boff[FT], aidx[FT], bidx[FT];
+  f32x16 acc[FT];
 #pragma unroll
-  for (int i = 0; i < F_MAXT; ++i) {
+  for (int i = 0; i < FT; ++i) {
     const int tt = (i < ntw) ? wave + 4 * i : wave;
     const int ct = tt / RT, rt = tt - ct * RT;
     aoff[i] = rt * 32;
     boff[i] = ct * 32;
+    aidx[i] = AS0 + hi * SA + r + aoff[i];
+    bidx[i] = BS0 + hi * F_SB + r + boff[i];
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
   }
 
-  // coupling tile: Mt[el][j] = coupling[e0+el, m_base + j]
-  for (int i = t; i < ecnt * m_len; i += 256) {
+  // coupling tile: Mt[el][j] = coupling[e0+el, m_base + j]; rows of edges beyond the graph are zero
+  for (int i = t; i < F_TE * m_len; i += 256) {
     const int el = i / m_len, j = i - el * m_len;
-    Mt[i] = g.c.coupling[(long)(e0 + el) * g.c.m_ld + D.m_base + j];
+    sfc_lds[MT0 + i] = (el < ecnt) ? g.c.coupling[(long)(e0 + el) * g.c.m_ld + D.m_base + j] : 0.f;
   }
 
+  // per-thread edge offsets (clamped: out-of-range edges read a valid row and are masked by vmask)
+  // edge of slot p: e0 + min(grp + 8p, ecnt - 1)  (recomputed where needed instead of held in registers)
+  const int elast = ecnt - 1;
+  const unsigned x_ld = g.c.x_ld, w_ld = g.c.w_ld;
+
   float xv[F_NP][MAXD], wv[F_NP];
-  float4 bv[F_MAXCT];
+  f32x4 bv[CTCAP];
   int s_d1 = 0, s_mo = 0;  // of the slab whose inputs are in xv / wv / bv
-  auto issue = [&](int s) {
+  auto load_x = [&](auto tag, const SfcSlab& S) __attribute__((always_inline)) {
+    constexpr int D1 = decltype(tag)::value;
+    const float* xs = g.c.x + S.x_off;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+      const float* xi = xs + i * S.x_mul;
+#pragma unroll
+      for (int p = 0; p < F_NP; ++p) xv[p][i] = xi[(unsigned)(e0 + min(grp + 8 * p, elast)) * x_ld + u];
+    }
+  };
+  auto issue = [&](int s) __attribute__((always_inline)) {
     const SfcSlab S = g.c.slab[D.slab0 + s];
     s_d1 = S.d1;
     s_mo = S.m_off - D.m_base;
+    if (g.c.w) {
+      const float* ws = g.c.w + S.w_off;
 #pragma unroll
-    for (int p = 0; p < F_NP; ++p) {
-      const int el = grp + 8 * p;
-      wv[p] = 0.f;
+      for (int p = 0; p < F_NP; ++p) wv[p] = ws[(unsigned)(e0 + min(grp + 8 * p, elast)) * w_ld + u];
+    } else {
 #pragma unroll
-      for (int i = 0; i < MAXD; ++i) xv[p][i] = 0.f;
-      if (el < ecnt) {
-        const long e = e0 + el;
-        wv[p] = g.c.w ? g.c.w[e * g.c.w_ld + S.w_off + u] : 1.0f;
-        const float* xp = g.c.x + e * g.c.x_ld + S.x_off + u;
-#pragma unroll
-        for (int i = 0; i < MAXD; ++i)
-          if (i < S.d1) xv[p][i] = xp[i * S.x_mul];
-      }
+      for (int p = 0; p < F_NP; ++p) wv[p] = 1.0f;
     }
+    switch (S.d1) {
+      case 1: load_x(IC<1>(), S); break;
+      case 3: load_x(IC<3>(), S); break;
+      case 5: load_x(IC<(MAXD >= 5 ? 5 : 1)>(), S); break;
+      default: load_x(IC<(MAXD >= 7 ? 7 : 1)>(), S); break;
+    }
+    // column blocks beyond CT re-read the last valid block (their LDS columns are never used): no guards, no
+    // dynamic indexing of bv
     const float* wp = D.W + (long)(s * 32 + (t >> 3)) * D.Ncat + ncol0 + 4 * (t & 7);
 #pragma unroll
-    for (int j = 0; j < F_MAXCT; ++j) {
-      bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < CT) bv[j] = *reinterpret_cast<const float4*>(wp + 32 * j);
-    }
+    for (int j = 0; j < CTCAP; ++j) bv[j] = *reinterpret_cast<const f32x4*>(wp + 32 * (j < CT ? j : CT - 1));
   };
-  auto commit = [&]() {
-    // rows of edges beyond the graph get zeros (xv = wv = 0), so As is always fully defined
+  const int awb = AS0 + u * SA + grp;
+  const int mrow = MT0 + grp * m_len;
+  auto gen = [&](auto tag) __attribute__((always_inline)) {
+    constexpr int D1 = decltype(tag)::value;
 #pragma unroll
     for (int p = 0; p < F_NP; ++p) {
-      const int el = grp + 8 * p;
-      const float* mp = Mt + (el < ecnt ? el : 0) * m_len + s_mo;
-      float* q = As + u * SA + el;
-      for (int m3 = 0; m3 < d3; ++m3) {
+      const int mp = mrow + (8 * p) * m_len + s_mo;
+      const float wm = (grp + 8 * p < ecnt) ? wv[p] : 0.f;
+#pragma unroll
+      for (int m3 = 0; m3 < D3; ++m3) {
         float a = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXD; ++i)
-          if (i < s_d1) a = fmaf(mp[i * d3 + m3], xv[p][i], a);
-        q[m3 * F_TE] = a * wv[p];
+        for (int i = 0; i < D1; ++i) a = fmaf(sfc_lds[mp + i * D3 + m3], xv[p][i], a);
+        sfc_lds[awb + 8 * p + m3 * F_TE] = a * wm;
       }
     }
-    float* bp = Bs + (t >> 3) * SB + 4 * (t & 7);
+  };
+  const int bwp = BS0 + (t >> 3) * F_SB + 4 * (t & 7);
+  auto commit = [&]() __attribute__((always_inline)) {
+    switch (s_d1) {
+      case 1: gen(IC<1>()); break;
+      case 3: gen(IC<3>()); break;
+      case 5: gen(IC<(MAXD >= 5 ? 5 : 1)>()); break;
+      default: gen(IC<(MAXD >= 7 ? 7 : 1)>()); break;
+    }
 #pragma unroll
-    for (int j = 0; j < F_MAXCT; ++j)
-      if (j < CT) *reinterpret_cast<float4*>(bp + 32 * j) = bv[j];
+    for (int j = 0; j < CTCAP; ++j) *reinterpret_cast<f32x4*>(&sfc_lds[bwp + 32 * j]) = bv[j];
   };
 
   issue(0);
@@ -183,26 +245,20 @@ __global__ __launch_bounds__(256, 2) void sfc_fwd_kernel(const SfcFwdArgs g) {
     commit();
     __syncthreads();
     if (s + 1 < nslab) issue(s + 1);
-#pragma unroll 2
-    for (int kk = 0; kk < 32; kk += 2) {
-      const float* ap = As + (kk + hi) * SA + r;
-      const float* bp = Bs + (kk + hi) * SB + r;
-      float av[F_MAXT], bw[F_MAXT];
-#pragma unroll
-      for (int i = 0; i < F_MAXT; ++i) {
-        av[i] = ap[aoff[i]];
-        bw[i] = bp[boff[i]];
-      }
-#pragma unroll
-      for (int i = 0; i < F_MAXT; ++i)
-        if (i < ntw) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bw[i], acc[i], 0, 0, 0);
+    switch (NT) {
+      case 1: f_mma<D3, 1, FT>(aidx, bidx, acc); break;
+      case 2: f_mma<D3, 2, FT>(aidx, bidx, acc); break;
+      case 3: f_mma<D3, 3, FT>(aidx, bidx, acc); break;
+      default:
+        if constexpr (FT >= 4) f_mma<D3, 4, FT>(aidx, bidx, acc);
+        break;
     }
     __syncthreads();
   }
 
   // epilogue: row = m3 * 64 + el ; column c of the concatenated output
 #pragma unroll
-  for (int i = 0; i < F_MAXT; ++i) {
+  for (int i = 0; i < FT; ++i) {
     if (i >= ntw) continue;
     const int c = ncol0 + boff[i] + r;
     const float bvl = (g.bias && D.l3 == 0) ? g.bias[c] : 0.f;
@@ -223,6 +279,21 @@ __global__ __launch_bounds__(256, 2) void sfc_fwd_kernel(const SfcFwdArgs g) {
   }
 }
 
+template <int MAXD>
+__global__ __launch_bounds__(256, (MAXD <= 5 ? 2 : 1)) void sfc_fwd_kernel(const SfcFwdArgs g) {
+  int b = blockIdx.x, di = 0;
+  while (di + 1 < g.c.ndeg && b >= g.blk0[di + 1]) ++di;
+  b -= g.blk0[di];
+  switch (g.c.deg[di].d3) {
+    case 1: f_block<1, MAXD>(g, di, b); break;
+    case 3: f_block<3, MAXD>(g, di, b); break;
+    case 5: f_block<5, MAXD>(g, di, b); break;
+    default:
+      if constexpr (MAXD >= 7) f_block<7, MAXD>(g, di, b);
+      break;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct SfcWgArgs {
   SfcCommon c;
@@ -235,6 +306,86 @@ struct SfcWgArgs {
 
 constexpr int W_SUB = 32;  // edges whose coupling matrices a wave keeps in LDS at a time
 
+// One wave, one private edge range [ebeg, eend): acc[ct] += mid^T (32 channels x edges*m3) * d_out (edges*m3 x 32 cols)
+template <int D1, int D3, int CTT>
+__device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, const SfcDeg& D, const int col0,
+                                        const int CT, float* __restrict__ Mw, const int ebeg, const int eend,
+                                        f32x16 (&acc)[CTT]) {
+  constexpr int LEN = D1 * D3;
+  const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+  const int N1 = D.N1;
+  // Uniform (scalar) base pointer per 32-column tile: a tile lies entirely in the main consumer's columns or in the
+  // second consumer's (N1 % 32 == 0 is checked on the host); per-lane offsets are 32-bit.
+  const float* cb[CTT];
+  unsigned cld[CTT], cm3[CTT];
+#pragma unroll
+  for (int ct = 0; ct < CTT; ++ct) {
+    const int c0 = col0 + (ct < CT ? ct : 0) * 32;
+    if (c0 < N1) {
+      cb[ct] = g.c.o1 + D.out1_off + c0, cld[ct] = g.c.ld1, cm3[ct] = N1;
+    } else {
+      cb[ct] = g.c.o2 + (c0 - N1), cld[ct] = g.c.ld2, cm3[ct] = 0;
+    }
+  }
+  const float* xs = g.c.x + S.x_off;
+  const float* ws = g.c.w ? g.c.w + S.w_off : nullptr;
+  const unsigned x_ld = g.c.x_ld, w_ld = g.c.w_ld, x_mul = S.x_mul;
+
+  float xn[D1], wn, bn[D3][CTT];  // prefetched raw inputs of the next edge pair
+  auto fetch = [&](int e) __attribute__((always_inline)) {
+    const int ee = e + hi;
+    const bool valid = ee < eend;
+    const unsigned er = valid ? ee : e;
+    const unsigned xo = er * x_ld + r;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xn[i] = xs[xo + i * x_mul];
+    wn = ws ? ws[er * w_ld + r] : 1.0f;
+    if (!valid) wn = 0.f;
+#pragma unroll
+    for (int m3 = 0; m3 < D3; ++m3)
+#pragma unroll
+      for (int ct = 0; ct < CTT; ++ct) bn[m3][ct] = cb[ct][er * cld[ct] + r + m3 * cm3[ct]];
+  };
+  auto stage_m = [&](int s0) __attribute__((always_inline)) {
+    __builtin_amdgcn_wave_barrier();
+    for (int el = 0; el < W_SUB; ++el) {
+      const int e = s0 + el;
+      if (e < eend && lane < LEN) Mw[el * LEN + lane] = g.c.coupling[(long)e * g.c.m_ld + S.m_off + lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  int sub0 = ebeg;
+  stage_m(sub0);
+  fetch(ebeg);
+  for (int e = ebeg; e < eend; e += 2) {
+    if (e >= sub0 + W_SUB) {
+      sub0 = e;
+      stage_m(sub0);
+    }
+    // form the A values of this pair from the prefetched x, w and the LDS-resident coupling matrices
+    const int ee = (e + hi < eend) ? e + hi : e;
+    const float* mp = Mw + (ee - sub0) * LEN;
+    float a[D3], bc[D3][CTT];
+#pragma unroll
+    for (int m3 = 0; m3 < D3; ++m3) {
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < D1; ++i) v = fmaf(mp[i * D3 + m3], xn[i], v);
+      a[m3] = v * wn;
+#pragma unroll
+      for (int ct = 0; ct < CTT; ++ct) bc[m3][ct] = bn[m3][ct];
+    }
+    if (e + 2 < eend) fetch(e + 2);  // in flight while the matrix pipe works on this pair
+#pragma unroll
+    for (int m3 = 0; m3 < D3; ++m3)
+#pragma unroll
+      for (int ct = 0; ct < CTT; ++ct)  // no guards here: a conditional MFMA makes hipcc shuttle the accumulators
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m3], bc[m3][ct], acc[ct], 0, 0, 0);
+  }
+}
+
 template <int CTT, int MAXD>
 __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
   __shared__ float Msh[4][W_SUB * MAXD * MAXD];  // per wave: [edge][i*d3 + m3] of the slab's path
@@ -244,13 +395,11 @@ __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
   const int col0 = g.item_col0[item], CT = g.item_ct[item];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
-  const int d1 = S.d1, d3 = D.d3, len = d1 * d3;
-  float* __restrict__ Mw = Msh[wave];
   // edge range of this wave (even start)
-  const int eb = blockIdx.x * g.echunk;
   const int per = g.echunk >> 2;
-  const int ebeg = eb + wave * per;
+  const int ebeg = blockIdx.x * g.echunk + wave * per;
   const int eend = min(g.c.E, ebeg + per);
+  if (ebeg >= eend) return;
 
   f32x16 acc[CTT];
 #pragma unroll
@@ -258,99 +407,27 @@ __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 
-  const int N1 = D.N1;
-  if (ebeg >= eend) return;
-  // Flattened loop over (edge pair, m3).  The raw inputs of step it+1 (d_out values and -- when a new edge pair
-  // starts -- x and w) are requested BEFORE the MFMAs of step it are issued, so their latency hides behind the matrix
-  // pipe; the A value of step it+1 is formed after those MFMAs.  Coupling matrices come from a wave-private LDS
-  // block refreshed every W_SUB edges (lane-uniform reads instead of d1*d3 vector loads per step).
-  float xv[MAXD], wv = 0.f;          // current edge pair
-  float xn[MAXD], wn = 0.f;          // next edge pair (prefetched)
-  float bn[CTT];                     // d_out values of the next step
-  float a_cur = 0.f, b_cur[CTT];
-  int sub0 = ebeg;                   // first edge of the LDS-resident coupling block
-  auto stage_m = [&](int s0) {
-    __builtin_amdgcn_wave_barrier();
-    for (int el = 0; el < W_SUB; ++el) {
-      const int e = s0 + el;
-      if (e < eend && lane < len) Mw[el * len + lane] = g.c.coupling[(long)e * g.c.m_ld + S.m_off + lane];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-  auto load_edge = [&](int e) {
-    const int ee = e + hi;
-    const bool valid = ee < eend;
-#pragma unroll
-    for (int i = 0; i < MAXD; ++i) xn[i] = 0.f;
-    wn = 0.f;
-    if (valid) {
-      const float* xp = g.c.x + (long)ee * g.c.x_ld + S.x_off + r;
-#pragma unroll
-      for (int i = 0; i < MAXD; ++i)
-        if (i < d1) xn[i] = xp[i * S.x_mul];
-      wn = g.c.w ? g.c.w[(long)ee * g.c.w_ld + S.w_off + r] : 1.0f;
-    }
-  };
-  auto take_edge = [&]() {
-#pragma unroll
-    for (int i = 0; i < MAXD; ++i) xv[i] = xn[i];
-    wv = wn;
-  };
-  auto load_step = [&](int e, int m3) {
-    const int ee = e + hi;
-    const bool valid = ee < eend;
-    const long er = valid ? ee : e;
-    const float* o1p = g.c.o1 + er * g.c.ld1 + D.out1_off + m3 * N1;
-    const float* o2p = g.c.o2 ? g.c.o2 + er * g.c.ld2 : nullptr;
-#pragma unroll
-    for (int ct = 0; ct < CTT; ++ct) {
-      bn[ct] = 0.f;
-      if (ct < CT && valid) {
-        const int c = col0 + ct * 32 + r;
-        bn[ct] = (c < N1) ? o1p[c] : o2p[c - N1];
-      }
-    }
-  };
-  auto form = [&](int e, int m3) {
-    const int ee = e + hi;
-    const float* mp = Mw + (ee < eend ? ee - sub0 : 0) * len + m3;
-    float a = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXD; ++i)
-      if (i < d1) a = fmaf(mp[i * d3], xv[i], a);
-    a_cur = a * wv;  // wv = 0 for the padding lane half
-#pragma unroll
-    for (int ct = 0; ct < CTT; ++ct) b_cur[ct] = bn[ct];
-  };
-  int e = ebeg, m3 = 0;
-  stage_m(sub0);
-  load_edge(e);
-  take_edge();
-  load_step(e, 0);
-  form(e, 0);
-  while (true) {
-    int en = e, mnext = m3 + 1;
-    if (mnext == d3) mnext = 0, en = e + 2;
-    const bool more = en < eend;
-    if (more) {
-      if (mnext == 0) load_edge(en);
-      load_step(en, mnext);
-    }
-#pragma unroll
-    for (int ct = 0; ct < CTT; ++ct)
-      if (ct < CT) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[ct], acc[ct], 0, 0, 0);
-    if (!more) break;
-    if (mnext == 0) {
-      take_edge();
-      if (en >= sub0 + W_SUB) {
-        sub0 = en;
-        stage_m(sub0);
-      }
-    }
-    form(en, mnext);
-    e = en, m3 = mnext;
+#define WG_CASE(A, B) wg_wave<A, B, CTT>(g, S, D, col0, CT, Msh[wave], ebeg, eend, acc)
+#define WG_D3(A)                                                    \
+  if constexpr (CTT > 4) { /* wide items: scalar degrees only */    \
+    WG_CASE(A, 1); /* the host routes only d3 == 1 degrees here */  \
+  } else {                                                          \
+    switch (D.d3) {                                                 \
+      case 1: WG_CASE(A, 1); break;                                 \
+      case 3: WG_CASE(A, (MAXD >= 3 ? 3 : 1)); break;               \
+      case 5: WG_CASE(A, (MAXD >= 5 ? 5 : 1)); break;               \
+      default: WG_CASE(A, (MAXD >= 7 ? 7 : 1)); break;              \
+    }                                                               \
   }
+  switch (S.d1) {
+    case 1: WG_D3(1); break;
+    case 3: WG_D3((MAXD >= 3 ? 3 : 1)); break;
+    case 5: WG_D3((MAXD >= 5 ? 5 : 1)); break;
+    default: WG_D3((MAXD >= 7 ? 7 : 1)); break;
+  }
+#undef WG_D3
+#undef WG_CASE
+
   // C[i = channel of the slab][j = column]
   const int slab_in_deg = g.item_slab[item] - D.slab0;
 #pragma unroll
@@ -370,8 +447,6 @@ constexpr int B_TE = 32;
 constexpr int B_KC = 256;         // columns of d_out staged per chunk
 constexpr int B_MAXGRP = 12;
 constexpr int B_MAXPATH = 12;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SfcBPath {
   short deg;    // index into deg[]
@@ -393,6 +468,7 @@ struct SfcBwdArgs {
   float* dM;  // may be null; ACCUMULATED with atomics
   int ngrp;
   int dt_floats;  // LDS partition
+  int full_m;     // the LDS coupling block holds whole coupling rows (mt_len == m_ld, mt_off == m_off)
   SfcBGroup grp[B_MAXGRP];
 };
 
@@ -400,12 +476,10 @@ struct SfcBwdArgs {
 // d_mid tile of a path for (16 edges x 16 channels x all m3) = d_out tile (LDS, [k][m3*32+el]) x W_slab^T with
 // v_mfma_f32_16x16x4_f32; its accumulator layout (lane = channel, 4 edges per lane) is exactly what the DTP backward
 // contraction wants, so the epilogue runs in registers: no exchange of d_mid between waves at all.
-template <int MAXD>
-__global__ __launch_bounds__(256, 2) void sfc_bwd_kernel(const SfcBwdArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int D1, int MAXD>
+__device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G, float* __restrict__ smem) {
   float* __restrict__ Dt = smem;                // [k][32*d3 + 4]
   float* __restrict__ Mt = smem + g.dt_floats;  // [32][mt_len]
-  const SfcBGroup& G = g.grp[blockIdx.y];
   const int e0 = blockIdx.x * B_TE;
   const int ecnt = min(B_TE, g.c.E - e0);
   const int t = threadIdx.x;
@@ -414,131 +488,193 @@ __global__ __launch_bounds__(256, 2) void sfc_bwd_kernel(const SfcBwdArgs g) {
   const int eh = wave & 1, chh = wave >> 1;
   const int ch = 16 * chh + j;         // channel inside the chunk
   const int el0 = 16 * eh + 4 * kg;    // first of this lane's 4 edges
-  const int d1 = G.d1, mt_len = G.mt_len;
+  const int mt_len = G.mt_len;
 
-  float xv[4][MAXD], gx[4][MAXD];
+  unsigned eo[4];   // clamped global edge index of this lane's edges
+  bool ev[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int el = el0 + q;
+    ev[q] = el0 + q < ecnt;
+    eo[q] = e0 + (ev[q] ? el0 + q : 0);
+  }
+  float xv[4][D1], gx[4][D1];
 #pragma unroll
-    for (int i = 0; i < MAXD; ++i) {
-      xv[q][i] = (el < ecnt && i < d1) ? g.c.x[(long)(e0 + el) * g.c.x_ld + G.x_off + i * G.x_mul + ch] : 0.f;
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+      xv[q][i] = ev[q] ? g.c.x[(long)eo[q] * g.c.x_ld + G.x_off + i * G.x_mul + ch] : 0.f;
       gx[q][i] = 0.f;
     }
-  }
-  // coupling matrices of the group's paths
-  for (int pi = 0; pi < G.npath; ++pi) {
-    const SfcBPath P = G.p[pi];
-    const int len = d1 * g.c.deg[P.deg].d3;
-    for (int i = t; i < B_TE * len; i += 256) {
-      const int el = i / len, jj = i - el * len;
-      Mt[el * mt_len + P.mt_off + jj] = (el < ecnt) ? g.c.coupling[(long)(e0 + el) * g.c.m_ld + P.m_off + jj] : 0.f;
+  // coupling matrices: either the whole (contiguous) coupling rows of the 32 edges in one coalesced pass, or -- when
+  // those do not fit (L_max = 3) -- only the matrices of the group's paths
+  if (g.full_m) {
+    const float* src = g.c.coupling + (long)e0 * g.c.m_ld;
+    for (int i = t; i < B_TE * mt_len; i += 256) Mt[i] = (i < ecnt * mt_len) ? src[i] : 0.f;
+  } else {
+    for (int pi = 0; pi < G.npath; ++pi) {
+      const SfcBPath P = G.p[pi];
+      const int len = D1 * g.c.deg[P.deg].d3;
+      for (int i = t; i < B_TE * len; i += 256) {
+        const int el = i / len, jj = i - el * len;
+        Mt[el * mt_len + P.mt_off + jj] = (el < ecnt) ? g.c.coupling[(long)(e0 + el) * g.c.m_ld + P.m_off + jj] : 0.f;
+      }
     }
   }
+  const float* const mrow = Mt + el0 * mt_len;
 
   int staged_deg = -1;
-  for (int pi = 0; pi < G.npath; ++pi) {
-    const SfcBPath P = G.p[pi];
+  float wcur[4], wnext[4];
+  auto load_w = [&](const SfcBPath& P, float (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = (ev[q] && g.c.w) ? g.c.w[(long)eo[q] * g.c.w_ld + P.w_off + ch] : 1.0f;
+  };
+  load_w(G.p[0], wcur);
+  auto path = [&](auto tag, const SfcBPath& P, const int pi) __attribute__((always_inline)) {
+    constexpr int D3 = decltype(tag)::value;
+    constexpr int ROWS = B_TE * D3, SD = ROWS + 4;
+    constexpr int RPT = ROWS / 16;                 // rows per thread and 64-column block when staging
+    constexpr int CBG = (RPT <= 2) ? 4 : 1;        // 64-column blocks loaded back to back (<= 14 float4 in flight)
     const SfcDeg& D = g.c.deg[P.deg];
-    const int d3 = D.d3, Ncat = D.Ncat, N1 = D.N1;
-    const int rows = B_TE * d3, SD = rows + 4;
-    float wv[4];
+    const int Ncat = D.Ncat, N1 = D.N1;
+    if (pi + 1 < G.npath) load_w(G.p[pi + 1], wnext);  // needed only by the next path's epilogue
+    f32x4 acc[2][D3];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      wv[q] = (el0 + q < ecnt && g.c.w) ? g.c.w[(long)(e0 + el0 + q) * g.c.w_ld + P.w_off + ch] : 1.0f;
-    f32x4 acc[2][MAXD];
-#pragma unroll
-    for (int i = 0; i < MAXD; ++i)
+    for (int i = 0; i < D3; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[0][i][q] = 0.f, acc[1][i][q] = 0.f;
 
     const int nchunk = (Ncat + B_KC - 1) / B_KC;
     for (int ck = 0; ck < nchunk; ++ck) {
       const int kc0 = ck * B_KC, kcn = min(B_KC, Ncat - kc0);
+      // MFMA k mapping: lane group kg supplies k = kb + 4 kg + jj for the jj-th instruction of a 16-wide k block
+      const float* wrow = D.W + (long)(P.krow + ch) * Ncat + kc0 + 4 * kg;
+      // weight fragments are prefetched PF k-blocks ahead (register rotation): with one row tile (D3 == 1) a k block
+      // is only 4 MFMAs = 128 cycles, far less than an L2 round trip
+      constexpr int PF = (D3 == 1) ? 4 : (D3 == 3 ? 2 : 1);
+      f32x4 bq[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        bq[u] = *reinterpret_cast<const f32x4*>(wrow + (16 * u < kcn ? 16 * u : 0));  // in flight across the staging
       if (!(nchunk == 1 && staged_deg == P.deg)) {
         __syncthreads();  // readers of the previous Dt contents are done
-        // stage Dt[k][row] = d_out[e0 + el, m3, kc0 + k],  row = m3*32 + el   (16 float4 columns x 4 rows per wave step)
+        // stage Dt[k][row] = d_out[e0 + el, m3, kc0 + k],  row = m3*32 + el.  A wave step covers 16 float4 columns x
+        // 4 rows; all loads of a group of column blocks are issued before the first LDS write.
         const int c4 = lane & 15, rr = lane >> 4;
-        for (int cb = 0; cb < kcn; cb += 64) {
-          const int c = cb + 4 * c4;
-          for (int rb = 0; rb < rows; rb += 16) {
-            const int row = rb + wave * 4 + rr;
-            if (c < kcn && row < rows) {
+        for (int cb0 = 0; cb0 < kcn; cb0 += 64 * CBG) {
+          f32x4 v[CBG][RPT];
+#pragma unroll
+          for (int cg_ = 0; cg_ < CBG; ++cg_) {
+            const int c = cb0 + 64 * cg_ + 4 * c4;
+            const int cg = kc0 + c;
+            const bool main = cg < N1;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+              const int row = 16 * i + wave * 4 + rr;
               const int m3 = row >> 5, el = row & 31;
-              float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (el < ecnt) {
-                const int cg = kc0 + c;
-                const float* src = (cg < N1) ? g.c.o1 + (long)(e0 + el) * g.c.ld1 + D.out1_off + m3 * N1 + cg
-                                             : g.c.o2 + (long)(e0 + el) * g.c.ld2 + (cg - N1);
-                v = *reinterpret_cast<const float4*>(src);
+              v[cg_][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (c < kcn && el < ecnt) {
+                const float* src = main ? g.c.o1 + (long)(e0 + el) * g.c.ld1 + D.out1_off + m3 * N1 + cg
+                                        : g.c.o2 + (long)(e0 + el) * g.c.ld2 + (cg - N1);
+                v[cg_][i] = *reinterpret_cast<const f32x4*>(src);
               }
-              float* q = Dt + c * SD + row;
-              q[0] = v.x, q[SD] = v.y, q[2 * SD] = v.z, q[3 * SD] = v.w;
+            }
+          }
+#pragma unroll
+          for (int cg_ = 0; cg_ < CBG; ++cg_) {
+            const int c = cb0 + 64 * cg_ + 4 * c4;
+            if (c < kcn) {
+#pragma unroll
+              for (int i = 0; i < RPT; ++i) {
+                float* q = Dt + c * SD + 16 * i + wave * 4 + rr;
+                q[0] = v[cg_][i][0], q[SD] = v[cg_][i][1], q[2 * SD] = v[cg_][i][2], q[3 * SD] = v[cg_][i][3];
+              }
             }
           }
         }
         staged_deg = P.deg;
         __syncthreads();
       }
-      // MFMA k mapping: lane group kg supplies k = kb + 4 kg + jj for the jj-th instruction of a 16-wide k block
-      const float* wrow = D.W + (long)(P.krow + ch) * Ncat + kc0 + 4 * kg;
-      const float* abase = Dt + (4 * kg) * SD + 16 * eh + j;
+      const float* ap = Dt + (4 * kg) * SD + 16 * eh + j;
+#pragma unroll 2
       for (int kb = 0; kb < kcn; kb += 16) {
-        const float4 b4 = *reinterpret_cast<const float4*>(wrow + kb);
-        const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
-        const float* ap = abase + kb * SD;
-        float av[4][MAXD];
+        const f32x4 b4 = bq[0];
+#pragma unroll
+        for (int u = 0; u + 1 < PF; ++u) bq[u] = bq[u + 1];
+        {
+          const int kn = kb + 16 * PF;
+          bq[PF - 1] = *reinterpret_cast<const f32x4*>(wrow + (kn < kcn ? kn : 0));
+        }
+        float av[4][D3];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int rt = 0; rt < MAXD; ++rt) av[jj][rt] = (rt < d3) ? ap[jj * SD + rt * 32] : 0.f;
+          for (int rt = 0; rt < D3; ++rt) av[jj][rt] = ap[jj * SD + rt * 32];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int rt = 0; rt < MAXD; ++rt)
-            if (rt < d3)
-              acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][rt], bj[jj], acc[jj & 1][rt], 0, 0, 0);
+          for (int rt = 0; rt < D3; ++rt)
+            acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][rt], b4[jj], acc[jj & 1][rt], 0, 0, 0);
+        ap += 16 * SD;
       }
     }
+    float wv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wv[q] = wcur[q], wcur[q] = wnext[q];
     // DTP backward contraction in registers: this lane holds d_mid[m3][edge el0+q][channel ch]
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int el = el0 + q;
       float gw = 0.f;
-      const float* mp = Mt + el * mt_len + P.mt_off;
+      const float* mp = mrow + q * mt_len + P.mt_off;
 #pragma unroll
-      for (int m3 = 0; m3 < MAXD; ++m3)
-        if (m3 < d3) {
-          const float dm = acc[0][m3][q] + acc[1][m3][q];
-          float tm = 0.f;
+      for (int m3 = 0; m3 < D3; ++m3) {
+        const float dm = acc[0][m3][q] + acc[1][m3][q];
+        const float dmw = dm * wv[q];
+        float tm = 0.f;
 #pragma unroll
-          for (int i = 0; i < MAXD; ++i)
-            if (i < d1) {
-              const float m = mp[i * d3 + m3];
-              tm = fmaf(m, xv[q][i], tm);
-              gx[q][i] = fmaf(m * wv[q], dm, gx[q][i]);
-              if (g.dM) {
-                float v = wv[q] * xv[q][i] * dm;  // sum over the 16 channels of this wave (lanes j)
-                v += __shfl_xor(v, 8);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 1);
-                if (j == 0 && el < ecnt) atomicAdd(g.dM + (long)(e0 + el) * g.c.m_ld + P.m_off + i * d3 + m3, v);
-              }
-            }
-          gw = fmaf(dm, tm, gw);
+        for (int i = 0; i < D1; ++i) {
+          const float m = mp[i * D3 + m3];
+          tm = fmaf(m, xv[q][i], tm);
+          gx[q][i] = fmaf(m, dmw, gx[q][i]);
+          if (g.dM) {
+            float v = dmw * xv[q][i];  // sum over the 16 channels of this wave (lanes j)
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            if (j == 0 && ev[q]) atomicAdd(g.dM + (long)eo[q] * g.c.m_ld + P.m_off + i * D3 + m3, v);
+          }
         }
-      if (g.dw && el < ecnt) g.dw[(long)(e0 + el) * g.c.w_ld + P.w_off + ch] = gw;
+        gw = fmaf(dm, tm, gw);
+      }
+      if (g.dw && ev[q]) g.dw[(long)eo[q] * g.c.w_ld + P.w_off + ch] = gw;
+    }
+  };
+
+  for (int pi = 0; pi < G.npath; ++pi) {
+    const SfcBPath P = G.p[pi];
+    switch (g.c.deg[P.deg].d3) {
+      case 1: path(IC<1>(), P, pi); break;
+      case 3: path(IC<3>(), P, pi); break;
+      case 5: path(IC<(MAXD >= 5 ? 5 : 1)>(), P, pi); break;
+      default: path(IC<(MAXD >= 7 ? 7 : 1)>(), P, pi); break;
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int el = el0 + q;
-    if (el < ecnt) {
+  for (int q = 0; q < 4; ++q)
+    if (ev[q]) {
 #pragma unroll
-      for (int i = 0; i < MAXD; ++i)
-        if (i < d1) g.dx[(long)(e0 + el) * g.c.x_ld + G.x_off + i * G.x_mul + ch] = gx[q][i];
+      for (int i = 0; i < D1; ++i) g.dx[(long)eo[q] * g.c.x_ld + G.x_off + i * G.x_mul + ch] = gx[q][i];
     }
+}
+
+template <int MAXD>
+__global__ __launch_bounds__(256, (MAXD <= 5 ? 2 : 1)) void sfc_bwd_kernel(const SfcBwdArgs g) {
+  const SfcBGroup& G = g.grp[blockIdx.y];
+  switch (G.d1) {
+    case 1: b_block<1, MAXD>(g, G, sfc_lds); break;
+    case 3: b_block<3, MAXD>(g, G, sfc_lds); break;
+    case 5: b_block<(MAXD >= 5 ? 5 : 1), MAXD>(g, G, sfc_lds); break;
+    default: b_block<(MAXD >= 7 ? 7 : 1), MAXD>(g, G, sfc_lds); break;
   }
 }
 
@@ -568,7 +704,7 @@ int build_common(const float* x, const float* coupling, const float* w, const eq
     D.Ncat = D.N1 + D.N2;
     D.out1_off = off;
     off += D.N1 * D.d3;
-    if (D.l3 > 3 || D.Ncat % 32 != 0 || D.N1 % 4 != 0) return EQF_E_UNSUPPORTED;
+    if (D.l3 > 3 || D.Ncat % 32 != 0 || D.N1 % 32 != 0) return EQF_E_UNSUPPORTED;
     D.W = Wl ? Wl[D.l3] : nullptr;
     D.dW = dWl ? dWl[D.l3] : nullptr;
     int K = 0, m_lo = 1 << 30, m_hi = 0;
@@ -638,6 +774,9 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
   if (rc) return rc;
   if (E <= 0) return 0;
   A.bias = bias0;
+  int md = max_d1(A.c);
+  for (int d = 0; d < A.c.ndeg; ++d) md = A.c.deg[d].d3 > md ? A.c.deg[d].d3 : md;
+  const int ft = md <= 5 ? 3 : F_MAXT;
   const int ntile = eqf_cdiv(E, F_TE);
   size_t lds = 0;
   int blk = 0;
@@ -646,20 +785,20 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
     const SfcDeg& D = A.c.deg[d];
     if (!D.W) return EQF_E_BADARG;
     const int RT = F_TE * D.d3 / 32;
-    int maxct = (4 * F_MAXT) / RT;  // tiles per workgroup <= 4 waves x F_MAXT
-    if (maxct > F_MAXCT) maxct = F_MAXCT;
+    (void)RT;
+    int maxct = f_ctcap(D.d3, ft);  // tiles per workgroup <= 4 waves x accumulator tiles per wave
     if (maxct < 1) return EQF_E_UNSUPPORTED;
     const int cttot = D.Ncat / 32;
     A.nsplit[d] = eqf_cdiv(cttot, maxct);
     A.cps[d] = eqf_cdiv(cttot, A.nsplit[d]) * 32;
     A.blk0[d] = blk;
     blk += ntile * A.nsplit[d];
-    const size_t need = sizeof(float) * (32 * (F_TE * D.d3 + 1) + 4 + 32 * (A.cps[d] + 4) + (size_t)F_TE * D.m_len);
+    const size_t need = sizeof(float) * (32 * (F_TE * D.d3 + 1) + 32 * f_sb(D.d3, ft) + (size_t)F_TE * D.m_len);
     if (need > lds) lds = need;
   }
   A.blk0[A.c.ndeg] = blk;
   if (lds > SFC_LDS_LIMIT) return EQF_E_UNSUPPORTED;
-  const int md = max_d1(A.c);
+
   hipStream_t st = (hipStream_t)stream;
   const int pid = eqf_prof_begin("sfc_fwd", st, sfc_flops(A.c), sfc_bytes(A.c));
   if (md <= 5) {
@@ -691,31 +830,38 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
                         const_cast<float*>(d_out2), n2, E, A.c);
   if (rc) return rc;
   if (E <= 0) return 0;
-  const int md = max_d1(A.c);
+  int md = max_d1(A.c);
+  for (int d = 0; d < A.c.ndeg; ++d) md = A.c.deg[d].d3 > md ? A.c.deg[d].d3 : md;
   hipStream_t st = (hipStream_t)stream;
-  // three launches at most, by accumulator width (column tiles per item): <= 2, <= 4, <= 12
-  const int caps[3] = {2, 4, 12};
+  // Items = (slab, column range of CTT tiles) with CTT in {1, 2, 4, 8} fixed at compile time (8 only for scalar
+  // degrees); a degree with cttot column tiles is decomposed greedily, the last item may be padded (its surplus
+  // tiles recompute tile 0 and are dropped).  One launch per class.
   for (int d = 0; d < A.c.ndeg; ++d)
     if (!A.c.deg[d].dW) return EQF_E_BADARG;
   const int pid = eqf_prof_begin("sfc_wgrad", st, sfc_flops(A.c), sfc_bytes(A.c));
-  for (int cls = 0; cls < 3; ++cls) {
+  const int classes[4] = {8, 4, 2, 1};
+  for (int ci = 0; ci < 4; ++ci) {
+    const int cls = classes[ci];
     A.nitem = 0;
     for (int d = 0; d < A.c.ndeg; ++d) {
       const SfcDeg& D = A.c.deg[d];
-      const int cttot = D.Ncat / 32;
-      const int c = cttot <= caps[0] ? 0 : (cttot <= caps[1] ? 1 : 2);  // wide degrees are split into <= 12-tile items
-      if (c != cls) continue;
-      const int nsp = eqf_cdiv(cttot, caps[cls]);
-      const int per = eqf_cdiv(cttot, nsp);
-      for (int q = 0; q < D.nslab; ++q)
-        for (int s = 0; s < nsp; ++s) {
-          if (A.nitem >= 2 * SFC_MAX_SLABS) return EQF_E_UNSUPPORTED;
-          const int ct0 = s * per, ctn = (cttot - ct0 < per) ? cttot - ct0 : per;
-          A.item_slab[A.nitem] = (short)(D.slab0 + q);
-          A.item_col0[A.nitem] = (short)(ct0 * 32);
-          A.item_ct[A.nitem] = (short)ctn;
-          A.nitem++;
-        }
+      int ct0 = 0, rem = D.Ncat / 32;
+      while (rem > 0) {
+        int take, used;
+        if (D.d3 == 1 && rem >= 7) take = 8;
+        else if (rem >= 3) take = 4;
+        else take = rem;  // 1 or 2
+        used = rem < take ? rem : take;
+        if (take == cls)
+          for (int q = 0; q < D.nslab; ++q) {
+            if (A.nitem >= 2 * SFC_MAX_SLABS) return EQF_E_UNSUPPORTED;
+            A.item_slab[A.nitem] = (short)(D.slab0 + q);
+            A.item_col0[A.nitem] = (short)(ct0 * 32);
+            A.item_ct[A.nitem] = (short)used;
+            A.nitem++;
+          }
+        ct0 += used, rem -= used;
+      }
     }
     if (A.nitem == 0) continue;
     int z = eqf_cdiv(1024, A.nitem);
@@ -732,12 +878,14 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
     else                                                                                                   \
       hipLaunchKernelGGL((sfc_wgrad_kernel<CTT, 7>), grid, dim3(256), 0, st, A);                           \
   } while (0)
-    if (cls == 0)
-      LAUNCH_WG(2);
-    else if (cls == 1)
+    if (cls == 8)
+      LAUNCH_WG(8);
+    else if (cls == 4)
       LAUNCH_WG(4);
+    else if (cls == 2)
+      LAUNCH_WG(2);
     else
-      LAUNCH_WG(12);
+      LAUNCH_WG(1);
 #undef LAUNCH_WG
     EQF_CHECK_LAUNCH();
   }
@@ -805,6 +953,14 @@ int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, cons
       if (mt > mtmax) mtmax = mt;
       if (G.npath > 0) A.ngrp++;
     }
+  A.full_m = P->m_numel <= 192;  // 32 whole coupling rows <= 24 KB of LDS
+  if (A.full_m) {
+    mtmax = P->m_numel;
+    for (int gi = 0; gi < A.ngrp; ++gi) {
+      A.grp[gi].mt_len = (short)P->m_numel;
+      for (int q = 0; q < A.grp[gi].npath; ++q) A.grp[gi].p[q].mt_off = A.grp[gi].p[q].m_off;
+    }
+  }
   if (A.ngrp == 0) return EQF_E_BADARG;
   A.dt_floats = (int)((dtmax + 3) & ~(size_t)3);
   const size_t lds = sizeof(float) * ((size_t)A.dt_floats + (size_t)B_TE * mtmax);

@@ -353,7 +353,7 @@ class SeparableFCTP(nn.Module):
         bias = self.lin._bias()
         if use_fused is True and self.sfc_spec.supported:
             out = ops.sep_fctp(node_input, M, w, bias, self.sfc_spec, self.degree_weights())
-        elif use_fused == "legacy" and self.fused_spec is not None:
+        elif use_fused and self.fused_spec is not None:
             weight = self.folded_lin_weight() if internal else self.lin.tp.weight
             out = ops.dtp_linear(node_input, M, w, weight, bias, self.fused_spec)
         else:

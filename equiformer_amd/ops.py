@@ -666,10 +666,14 @@ class SfcSpec:
                 raise NotImplementedError("output degree %d is not produced by the tensor product" % l3)
             K = table.layout_out.segs[i][0]
             ncat = N1 + (self.n2 if l3 == 0 else 0)
-            ok = ok and ncat % 32 == 0 and N1 % 4 == 0 and l3 <= 3
+            ok = ok and ncat % 32 == 0 and N1 % 32 == 0 and l3 <= 3
             self.degs.append((l3, K, N1, ncat))
         if self.n2 and out_layout.seg_index(0) is None:
             ok = False
+        # LDS footprint of the forward workgroup (A tile + weight tile + coupling tile of 64 edges), see sfc.hip
+        for (l3, _, _, _) in self.degs:
+            m_len = sum((2 * p["l1"] + 1) * (2 * l3 + 1) for p in table.paths if p["l3"] == l3)
+            ok = ok and 4 * (32 * (64 * (2 * l3 + 1) + 1) + 32 * 68 + 64 * m_len) <= 160 * 1024
         self.supported = ok and len(self.degs) <= 4
         self.bias_dim = out_layout.mul_of(0) + self.n2
         used = {l3 for l3, _, _, _ in self.degs}
