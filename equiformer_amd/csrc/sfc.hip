@@ -32,6 +32,8 @@ extern __shared__ __attribute__((aligned(16))) float sfc_lds[];  // dynamic LDS 
 
 namespace {
 
+unsigned long long* g_sfc_dbg = nullptr;  // set by eqf_sfc_debug_buffer (development aid)
+
 constexpr int SFC_MAX_DEG = 4;
 constexpr int SFC_MAX_SLABS = 72;   // 32-channel slabs over all output degrees (DTP width <= 3072 channels)
 constexpr int SFC_MAX_D1 = 7;       // l1 <= 3
@@ -100,23 +102,33 @@ template <int D3, int NT, int FT>
 __device__ __forceinline__ void f_mma(const int (&aidx)[FT], const int (&bidx)[FT], f32x16 (&acc)[FT]) {
   constexpr int SA = F_TE * D3 + 1, F_SB = f_sb(D3, FT);
   int ai[NT], bi[NT];
+  float an[NT], bn[NT];  // operands of the next k pair, requested before the MFMAs of the current pair are issued
 #pragma unroll
-  for (int i = 0; i < NT; ++i) ai[i] = aidx[i], bi[i] = bidx[i];
+  for (int i = 0; i < NT; ++i) {
+    ai[i] = aidx[i], bi[i] = bidx[i];
+    an[i] = sfc_lds[ai[i]], bn[i] = sfc_lds[bi[i]];
+  }
 #pragma unroll 1
-  for (int kq = 0; kq < 4; ++kq) {  // 4 x (4 k-pairs): bounded unrolling keeps the operand registers in check
+  for (int kq = 0; kq < 4; ++kq) {  // 4 x (4 k-pairs): bounded unrolling keeps the code and the registers in check
 #pragma unroll
     for (int kk = 0; kk < 8; kk += 2) {
       float av[NT], bw[NT];
 #pragma unroll
+      for (int i = 0; i < NT; ++i) av[i] = an[i], bw[i] = bn[i];
+      const int nk = (kk + 2 < 8) ? kk + 2 : 6;  // last pair of the group: re-read (the next group reloads)
+#pragma unroll
       for (int i = 0; i < NT; ++i) {
-        av[i] = sfc_lds[ai[i] + kk * SA];
-        bw[i] = sfc_lds[bi[i] + kk * F_SB];
+        an[i] = sfc_lds[ai[i] + nk * SA];
+        bn[i] = sfc_lds[bi[i] + nk * F_SB];
       }
 #pragma unroll
       for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bw[i], acc[i], 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) ai[i] += 8 * SA, bi[i] += 8 * F_SB;
+    for (int i = 0; i < NT; ++i) {
+      ai[i] += 8 * SA, bi[i] += 8 * F_SB;
+      if (kq < 3) an[i] = sfc_lds[ai[i]], bn[i] = sfc_lds[bi[i]];
+    }
   }
 }
 
@@ -331,20 +343,23 @@ __device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, co
   const float* ws = g.c.w ? g.c.w + S.w_off : nullptr;
   const unsigned x_ld = g.c.x_ld, w_ld = g.c.w_ld, x_mul = S.x_mul;
 
-  float xn[D1], wn, bn[D3][CTT];  // prefetched raw inputs of the next edge pair
-  auto fetch = [&](int e) __attribute__((always_inline)) {
+  // raw inputs (x, w, d_out values) of the next PF edge pairs, rotated through registers: wide items run at one wave per
+  // SIMD, where only the wave's own look-ahead hides the memory latency behind its MFMAs
+  constexpr int PF = (CTT >= 4) ? 2 : 1;
+  float xq[PF][D1], wq[PF], bq[PF][D3][CTT];
+  auto fetch = [&](int e, int slot) __attribute__((always_inline)) {
     const int ee = e + hi;
     const bool valid = ee < eend;
-    const unsigned er = valid ? ee : e;
+    const unsigned er = valid ? ee : (e < eend ? e : ebeg);
     const unsigned xo = er * x_ld + r;
 #pragma unroll
-    for (int i = 0; i < D1; ++i) xn[i] = xs[xo + i * x_mul];
-    wn = ws ? ws[er * w_ld + r] : 1.0f;
-    if (!valid) wn = 0.f;
+    for (int i = 0; i < D1; ++i) xq[slot][i] = xs[xo + i * x_mul];
+    wq[slot] = ws ? ws[er * w_ld + r] : 1.0f;
+    if (!valid) wq[slot] = 0.f;
 #pragma unroll
     for (int m3 = 0; m3 < D3; ++m3)
 #pragma unroll
-      for (int ct = 0; ct < CTT; ++ct) bn[m3][ct] = cb[ct][er * cld[ct] + r + m3 * cm3[ct]];
+      for (int ct = 0; ct < CTT; ++ct) bq[slot][m3][ct] = cb[ct][er * cld[ct] + r + m3 * cm3[ct]];
   };
   auto stage_m = [&](int s0) __attribute__((always_inline)) {
     __builtin_amdgcn_wave_barrier();
@@ -358,7 +373,8 @@ __device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, co
 
   int sub0 = ebeg;
   stage_m(sub0);
-  fetch(ebeg);
+#pragma unroll
+  for (int u = 0; u < PF; ++u) fetch(ebeg + 2 * u, u);
   for (int e = ebeg; e < eend; e += 2) {
     if (e >= sub0 + W_SUB) {
       sub0 = e;
@@ -372,12 +388,22 @@ __device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, co
     for (int m3 = 0; m3 < D3; ++m3) {
       float v = 0.f;
 #pragma unroll
-      for (int i = 0; i < D1; ++i) v = fmaf(mp[i * D3 + m3], xn[i], v);
-      a[m3] = v * wn;
+      for (int i = 0; i < D1; ++i) v = fmaf(mp[i * D3 + m3], xq[0][i], v);
+      a[m3] = v * wq[0];
 #pragma unroll
-      for (int ct = 0; ct < CTT; ++ct) bc[m3][ct] = bn[m3][ct];
+      for (int ct = 0; ct < CTT; ++ct) bc[m3][ct] = bq[0][m3][ct];
     }
-    if (e + 2 < eend) fetch(e + 2);  // in flight while the matrix pipe works on this pair
+#pragma unroll
+    for (int u = 0; u + 1 < PF; ++u) {
+#pragma unroll
+      for (int i = 0; i < D1; ++i) xq[u][i] = xq[u + 1][i];
+      wq[u] = wq[u + 1];
+#pragma unroll
+      for (int m3 = 0; m3 < D3; ++m3)
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) bq[u][m3][ct] = bq[u + 1][m3][ct];
+    }
+    fetch(e + 2 * PF, PF - 1);  // in flight while the matrix pipe works; out-of-range pairs re-read a valid row, w = 0
 #pragma unroll
     for (int m3 = 0; m3 < D3; ++m3)
 #pragma unroll
@@ -389,6 +415,7 @@ __device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, co
 template <int CTT, int MAXD>
 __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
   __shared__ float Msh[4][W_SUB * MAXD * MAXD];  // per wave: [edge][i*d3 + m3] of the slab's path
+  __shared__ float Red[2][32 * CTT * 32];          // cross-wave reduction slots
   const int item = blockIdx.y;
   const SfcSlab S = g.c.slab[g.item_slab[item]];
   const SfcDeg& D = g.c.deg[S.deg];
@@ -399,7 +426,6 @@ __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
   const int per = g.echunk >> 2;
   const int ebeg = blockIdx.x * g.echunk + wave * per;
   const int eend = min(g.c.E, ebeg + per);
-  if (ebeg >= eend) return;
 
   f32x16 acc[CTT];
 #pragma unroll
@@ -410,7 +436,7 @@ __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
 #define WG_CASE(A, B) wg_wave<A, B, CTT>(g, S, D, col0, CT, Msh[wave], ebeg, eend, acc)
 #define WG_D3(A)                                                    \
   if constexpr (CTT > 4) { /* wide items: scalar degrees only */    \
-    WG_CASE(A, 1); /* the host routes only d3 == 1 degrees here */  \
+    WG_CASE(A, 1);                                                  \
   } else {                                                          \
     switch (D.d3) {                                                 \
       case 1: WG_CASE(A, 1); break;                                 \
@@ -419,15 +445,39 @@ __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
       default: WG_CASE(A, (MAXD >= 7 ? 7 : 1)); break;              \
     }                                                               \
   }
-  switch (S.d1) {
-    case 1: WG_D3(1); break;
-    case 3: WG_D3((MAXD >= 3 ? 3 : 1)); break;
-    case 5: WG_D3((MAXD >= 5 ? 5 : 1)); break;
-    default: WG_D3((MAXD >= 7 ? 7 : 1)); break;
+  if (ebeg < eend) {
+    switch (S.d1) {
+      case 1: WG_D3(1); break;
+      case 3: WG_D3((MAXD >= 3 ? 3 : 1)); break;
+      case 5: WG_D3((MAXD >= 5 ? 5 : 1)); break;
+      default: WG_D3((MAXD >= 7 ? 7 : 1)); break;
+    }
   }
 #undef WG_D3
 #undef WG_CASE
 
+  // sum the four waves' accumulators through LDS (tree: 2,3 -> 0,1 ; 1 -> 0), then ONE set of atomics per workgroup
+  constexpr int RW = CTT * 32;  // row length of a [32 channels][RW] slot
+  auto put = [&](float* slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) slot[((q & 3) + 8 * (q >> 2) + 4 * hi) * RW + ct * 32 + r] = acc[ct][q];
+  };
+  auto take = [&](const float* slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[ct][q] += slot[((q & 3) + 8 * (q >> 2) + 4 * hi) * RW + ct * 32 + r];
+  };
+  if (wave >= 2) put(Red[wave - 2]);
+  __syncthreads();
+  if (wave < 2) take(Red[wave]);
+  __syncthreads();
+  if (wave == 1) put(Red[0]);
+  __syncthreads();
+  if (wave != 0) return;
+  take(Red[0]);
   // C[i = channel of the slab][j = column]
   const int slab_in_deg = g.item_slab[item] - D.slab0;
 #pragma unroll
@@ -444,7 +494,7 @@ __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
 
 // ------------------------------------------------------------------------------------------------ data gradient
 constexpr int B_TE = 32;
-constexpr int B_KC = 256;         // columns of d_out staged per chunk
+constexpr int B_KC = 384;         // columns of d_out staged per chunk
 constexpr int B_MAXGRP = 12;
 constexpr int B_MAXPATH = 12;
 
@@ -457,8 +507,9 @@ struct SfcBPath {
   short pad;
 };
 struct SfcBGroup {
-  int x_off;   // offset of (segment l1, chunk) in the x row
+  int x_off;   // offset of (segment l1, first chunk) in the x row
   short x_mul, d1, npath, mt_len;
+  short nch, pad0;  // 32-channel chunks handled by the workgroup (1, 2 or 4; nch * d1 <= 6)
   SfcBPath p[B_MAXPATH];
 };
 struct SfcBwdArgs {
@@ -469,6 +520,7 @@ struct SfcBwdArgs {
   int ngrp;
   int dt_floats;  // LDS partition
   int full_m;     // the LDS coupling block holds whole coupling rows (mt_len == m_ld, mt_off == m_off)
+  unsigned long long* dbg;  // optional phase timers (cycles of wave 0 / lane 0 of every workgroup), may be null
   SfcBGroup grp[B_MAXGRP];
 };
 
@@ -476,7 +528,7 @@ struct SfcBwdArgs {
 // d_mid tile of a path for (16 edges x 16 channels x all m3) = d_out tile (LDS, [k][m3*32+el]) x W_slab^T with
 // v_mfma_f32_16x16x4_f32; its accumulator layout (lane = channel, 4 edges per lane) is exactly what the DTP backward
 // contraction wants, so the epilogue runs in registers: no exchange of d_mid between waves at all.
-template <int D1, int MAXD>
+template <int D1, int CG, int MAXD>
 __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G, float* __restrict__ smem) {
   float* __restrict__ Dt = smem;                // [k][32*d3 + 4]
   float* __restrict__ Mt = smem + g.dt_floats;  // [32][mt_len]
@@ -490,6 +542,14 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
   const int el0 = 16 * eh + 4 * kg;    // first of this lane's 4 edges
   const int mt_len = G.mt_len;
 
+  unsigned long long t_mark = g.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  auto tick = [&](int slot) __attribute__((always_inline)) {
+    if (g.dbg) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (t == 0) atomicAdd(g.dbg + slot, now - t_mark);
+      t_mark = now;
+    }
+  };
   unsigned eo[4];   // clamped global edge index of this lane's edges
   bool ev[4];
 #pragma unroll
@@ -497,14 +557,16 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
     ev[q] = el0 + q < ecnt;
     eo[q] = e0 + (ev[q] ? el0 + q : 0);
   }
-  float xv[4][D1], gx[4][D1];
+  float xv[CG][4][D1], gx[CG][4][D1];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int c = 0; c < CG; ++c)
 #pragma unroll
-    for (int i = 0; i < D1; ++i) {
-      xv[q][i] = ev[q] ? g.c.x[(long)eo[q] * g.c.x_ld + G.x_off + i * G.x_mul + ch] : 0.f;
-      gx[q][i] = 0.f;
-    }
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < D1; ++i) {
+        xv[c][q][i] = ev[q] ? g.c.x[(long)eo[q] * g.c.x_ld + G.x_off + 32 * c + i * G.x_mul + ch] : 0.f;
+        gx[c][q][i] = 0.f;
+      }
   // coupling matrices: either the whole (contiguous) coupling rows of the 32 edges in one coalesced pass, or -- when
   // those do not fit (L_max = 3) -- only the matrices of the group's paths
   if (g.full_m) {
@@ -521,132 +583,155 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
     }
   }
   const float* const mrow = Mt + el0 * mt_len;
+  tick(0);  // prologue: x loads issued, coupling tile staged
 
   int staged_deg = -1;
-  float wcur[4], wnext[4];
-  auto load_w = [&](const SfcBPath& P, float (&dst)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = (ev[q] && g.c.w) ? g.c.w[(long)eo[q] * g.c.w_ld + P.w_off + ch] : 1.0f;
-  };
-  load_w(G.p[0], wcur);
   auto path = [&](auto tag, const SfcBPath& P, const int pi) __attribute__((always_inline)) {
     constexpr int D3 = decltype(tag)::value;
     constexpr int ROWS = B_TE * D3, SD = ROWS + 4;
     constexpr int RPT = ROWS / 16;                 // rows per thread and 64-column block when staging
     constexpr int CBG = (RPT <= 2) ? 4 : 1;        // 64-column blocks loaded back to back (<= 14 float4 in flight)
+    // weight fragments are prefetched PF k-blocks ahead (register rotation): with one row tile (D3 == 1) a k block
+    // is only 4 MFMAs = 128 cycles, far less than an L2 round trip
+    constexpr int PF = (D3 == 1) ? 4 : (D3 == 3 ? 2 : 1);
     const SfcDeg& D = g.c.deg[P.deg];
     const int Ncat = D.Ncat, N1 = D.N1;
-    if (pi + 1 < G.npath) load_w(G.p[pi + 1], wnext);  // needed only by the next path's epilogue
-    f32x4 acc[2][D3];
-#pragma unroll
-    for (int i = 0; i < D3; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[0][i][q] = 0.f, acc[1][i][q] = 0.f;
-
     const int nchunk = (Ncat + B_KC - 1) / B_KC;
-    for (int ck = 0; ck < nchunk; ++ck) {
-      const int kc0 = ck * B_KC, kcn = min(B_KC, Ncat - kc0);
-      // MFMA k mapping: lane group kg supplies k = kb + 4 kg + jj for the jj-th instruction of a 16-wide k block
-      const float* wrow = D.W + (long)(P.krow + ch) * Ncat + kc0 + 4 * kg;
-      // weight fragments are prefetched PF k-blocks ahead (register rotation): with one row tile (D3 == 1) a k block
-      // is only 4 MFMAs = 128 cycles, far less than an L2 round trip
-      constexpr int PF = (D3 == 1) ? 4 : (D3 == 3 ? 2 : 1);
-      f32x4 bq[PF];
+    auto chunk = [&](auto ctag) __attribute__((always_inline)) {  // one 32-channel chunk: MFMA loop + register epilogue
+      constexpr int c = decltype(ctag)::value;
+      f32x4 acc[2][D3];
 #pragma unroll
-      for (int u = 0; u < PF; ++u)
-        bq[u] = *reinterpret_cast<const f32x4*>(wrow + (16 * u < kcn ? 16 * u : 0));  // in flight across the staging
-      if (!(nchunk == 1 && staged_deg == P.deg)) {
-        __syncthreads();  // readers of the previous Dt contents are done
-        // stage Dt[k][row] = d_out[e0 + el, m3, kc0 + k],  row = m3*32 + el.  A wave step covers 16 float4 columns x
-        // 4 rows; all loads of a group of column blocks are issued before the first LDS write.
-        const int c4 = lane & 15, rr = lane >> 4;
-        for (int cb0 = 0; cb0 < kcn; cb0 += 64 * CBG) {
-          f32x4 v[CBG][RPT];
+      for (int i = 0; i < D3; ++i)
 #pragma unroll
-          for (int cg_ = 0; cg_ < CBG; ++cg_) {
-            const int c = cb0 + 64 * cg_ + 4 * c4;
-            const int cg = kc0 + c;
-            const bool main = cg < N1;
+        for (int q = 0; q < 4; ++q) acc[0][i][q] = 0.f, acc[1][i][q] = 0.f;
+      float wv[4];
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-              const int row = 16 * i + wave * 4 + rr;
-              const int m3 = row >> 5, el = row & 31;
-              v[cg_][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-              if (c < kcn && el < ecnt) {
-                const float* src = main ? g.c.o1 + (long)(e0 + el) * g.c.ld1 + D.out1_off + m3 * N1 + cg
-                                        : g.c.o2 + (long)(e0 + el) * g.c.ld2 + (cg - N1);
-                v[cg_][i] = *reinterpret_cast<const f32x4*>(src);
-              }
-            }
-          }
+      for (int q = 0; q < 4; ++q)
+        wv[q] = (ev[q] && g.c.w) ? g.c.w[(long)eo[q] * g.c.w_ld + P.w_off + 32 * c + ch] : 1.0f;  // used in the epilogue
+
+      for (int ck = 0; ck < nchunk; ++ck) {
+        const int kc0 = ck * B_KC, kcn = min(B_KC, Ncat - kc0);
+        // MFMA k mapping: lane group kg supplies k = kb + 4 kg + jj for the jj-th instruction of a 16-wide k block
+        const float* wrow = D.W + (long)(P.krow + 32 * c + ch) * Ncat + kc0 + 4 * kg;
+        // weight fragments of the first two k blocks (kcn is a multiple of 32): in flight across the staging below
+        f32x4 bA = *reinterpret_cast<const f32x4*>(wrow);
+        f32x4 bB = *reinterpret_cast<const f32x4*>(wrow + 16);
+        if (!(nchunk == 1 && staged_deg == P.deg)) {
+          __syncthreads();  // readers of the previous Dt contents are done
+          // stage Dt[k][row] = d_out[e0 + el, m3, kc0 + k],  row = m3*32 + el.  A wave step covers 16 float4 columns x
+          // 4 rows; all loads of a group of column blocks are issued before the first LDS write.
+          const int c4 = lane & 15, rr = lane >> 4;
+          for (int cb0 = 0; cb0 < kcn; cb0 += 64 * CBG) {
+            f32x4 v[CBG][RPT];
 #pragma unroll
-          for (int cg_ = 0; cg_ < CBG; ++cg_) {
-            const int c = cb0 + 64 * cg_ + 4 * c4;
-            if (c < kcn) {
+            for (int cg_ = 0; cg_ < CBG; ++cg_) {
+              const int cc = cb0 + 64 * cg_ + 4 * c4;
+              const int cg = kc0 + cc;
+              const bool main = cg < N1;
 #pragma unroll
               for (int i = 0; i < RPT; ++i) {
-                float* q = Dt + c * SD + 16 * i + wave * 4 + rr;
-                q[0] = v[cg_][i][0], q[SD] = v[cg_][i][1], q[2 * SD] = v[cg_][i][2], q[3 * SD] = v[cg_][i][3];
+                const int row = 16 * i + wave * 4 + rr;
+                const int m3 = row >> 5, el = row & 31;
+                v[cg_][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (cc < kcn && el < ecnt) {
+                  const float* src = main ? g.c.o1 + (long)(e0 + el) * g.c.ld1 + D.out1_off + m3 * N1 + cg
+                                          : g.c.o2 + (long)(e0 + el) * g.c.ld2 + (cg - N1);
+                  v[cg_][i] = *reinterpret_cast<const f32x4*>(src);
+                }
+              }
+            }
+#pragma unroll
+            for (int cg_ = 0; cg_ < CBG; ++cg_) {
+              const int cc = cb0 + 64 * cg_ + 4 * c4;
+              if (cc < kcn) {
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                  float* q = Dt + cc * SD + 16 * i + wave * 4 + rr;
+                  q[0] = v[cg_][i][0], q[SD] = v[cg_][i][1], q[2 * SD] = v[cg_][i][2], q[3 * SD] = v[cg_][i][3];
+                }
               }
             }
           }
+          staged_deg = P.deg;
+          __syncthreads();
+          tick(1);  // staging of a d_out tile
         }
-        staged_deg = P.deg;
-        __syncthreads();
-      }
-      const float* ap = Dt + (4 * kg) * SD + 16 * eh + j;
-#pragma unroll 2
-      for (int kb = 0; kb < kcn; kb += 16) {
-        const f32x4 b4 = bq[0];
-#pragma unroll
-        for (int u = 0; u + 1 < PF; ++u) bq[u] = bq[u + 1];
-        {
-          const int kn = kb + 16 * PF;
-          bq[PF - 1] = *reinterpret_cast<const f32x4*>(wrow + (kn < kcn ? kn : 0));
-        }
-        float av[4][D3];
+        const float* ap = Dt + (4 * kg) * SD + 16 * eh + j;
+        // Two k blocks per iteration with statically named ping-pong registers (no register rotation, no copies): the
+        // LDS operands (aA / aB) and the weight fragments (bA / bB) of a block are requested one block / two blocks
+        // before its MFMAs are issued.
+        float aA[4][D3], aB[4][D3];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int rt = 0; rt < D3; ++rt) av[jj][rt] = ap[jj * SD + rt * 32];
+          for (int rt = 0; rt < D3; ++rt) aA[jj][rt] = ap[jj * SD + rt * 32];
+#pragma unroll 1
+        for (int kb = 0; kb < kcn; kb += 32) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+          for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int rt = 0; rt < D3; ++rt)
-            acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][rt], b4[jj], acc[jj & 1][rt], 0, 0, 0);
-        ap += 16 * SD;
+            for (int rt = 0; rt < D3; ++rt) aB[jj][rt] = ap[(16 + jj) * SD + rt * 32];
+          const f32x4 b0 = bA;
+          bA = *reinterpret_cast<const f32x4*>(wrow + (kb + 32 < kcn ? kb + 32 : 0));
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int rt = 0; rt < D3; ++rt)
+              acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[jj][rt], b0[jj], acc[jj & 1][rt], 0, 0, 0);
+          ap += (kb + 32 < kcn) ? 32 * SD : 0;  // the last iteration re-reads its own first block (harmless)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int rt = 0; rt < D3; ++rt) aA[jj][rt] = ap[jj * SD + rt * 32];
+          const f32x4 b1 = bB;
+          bB = *reinterpret_cast<const f32x4*>(wrow + (kb + 48 < kcn ? kb + 48 : 0));
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int rt = 0; rt < D3; ++rt)
+              acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[jj][rt], b1[jj], acc[jj & 1][rt], 0, 0, 0);
+        }
       }
-    }
-    float wv[4];
+      tick(2);  // MFMA loop
+      // DTP backward contraction in registers: this lane holds d_mid[m3][edge el0+q][channel 32c + ch]
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wv[q] = wcur[q], wcur[q] = wnext[q];
-    // DTP backward contraction in registers: this lane holds d_mid[m3][edge el0+q][channel ch]
+      for (int q = 0; q < 4; ++q) {
+        float gw = 0.f;
+        const float* mp = mrow + q * mt_len + P.mt_off;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float gw = 0.f;
-      const float* mp = mrow + q * mt_len + P.mt_off;
+        for (int m3 = 0; m3 < D3; ++m3) {
+          const float dm = acc[0][m3][q] + acc[1][m3][q];
+          const float dmw = dm * wv[q];
+          float tm = 0.f;
 #pragma unroll
-      for (int m3 = 0; m3 < D3; ++m3) {
-        const float dm = acc[0][m3][q] + acc[1][m3][q];
-        const float dmw = dm * wv[q];
-        float tm = 0.f;
-#pragma unroll
-        for (int i = 0; i < D1; ++i) {
-          const float m = mp[i * D3 + m3];
-          tm = fmaf(m, xv[q][i], tm);
-          gx[q][i] = fmaf(m, dmw, gx[q][i]);
-          if (g.dM) {
-            float v = dmw * xv[q][i];  // sum over the 16 channels of this wave (lanes j)
-            v += __shfl_xor(v, 8);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 1);
-            if (j == 0 && ev[q]) atomicAdd(g.dM + (long)eo[q] * g.c.m_ld + P.m_off + i * D3 + m3, v);
+          for (int i = 0; i < D1; ++i) {
+            const float m = mp[i * D3 + m3];
+            tm = fmaf(m, xv[c][q][i], tm);
+            gx[c][q][i] = fmaf(m, dmw, gx[c][q][i]);
+            if (g.dM) {
+              float v = dmw * xv[c][q][i];  // sum over the 16 channels of this wave (lanes j)
+              v += __shfl_xor(v, 8);
+              v += __shfl_xor(v, 4);
+              v += __shfl_xor(v, 2);
+              v += __shfl_xor(v, 1);
+              if (j == 0 && ev[q]) atomicAdd(g.dM + (long)eo[q] * g.c.m_ld + P.m_off + i * D3 + m3, v);
+            }
           }
+          gw = fmaf(dm, tm, gw);
         }
-        gw = fmaf(dm, tm, gw);
+        if (g.dw && ev[q]) g.dw[(long)eo[q] * g.c.w_ld + P.w_off + 32 * c + ch] = gw;
       }
-      if (g.dw && ev[q]) g.dw[(long)eo[q] * g.c.w_ld + P.w_off + ch] = gw;
+      tick(3);  // register epilogue
+    };
+    // a real loop (not unrolled) around a static dispatch: keeps the chunks' live ranges apart
+#pragma unroll 1
+    for (int c = 0; c < CG; ++c) {
+      switch (c) {
+        case 0: chunk(IC<0>()); break;
+        case 1: chunk(IC<(CG > 1 ? 1 : 0)>()); break;
+        case 2: chunk(IC<(CG > 2 ? 2 : 0)>()); break;
+        default: chunk(IC<(CG > 3 ? 3 : 0)>()); break;
+      }
     }
   };
 
@@ -660,21 +745,31 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (ev[q]) {
+  for (int c = 0; c < CG; ++c)
 #pragma unroll
-      for (int i = 0; i < D1; ++i) g.dx[(long)eo[q] * g.c.x_ld + G.x_off + i * G.x_mul + ch] = gx[q][i];
-    }
+    for (int q = 0; q < 4; ++q)
+      if (ev[q]) {
+#pragma unroll
+        for (int i = 0; i < D1; ++i) g.dx[(long)eo[q] * g.c.x_ld + G.x_off + 32 * c + i * G.x_mul + ch] = gx[c][q][i];
+      }
+  tick(4);  // dx stores
 }
 
 template <int MAXD>
 __global__ __launch_bounds__(256, (MAXD <= 5 ? 2 : 1)) void sfc_bwd_kernel(const SfcBwdArgs g) {
   const SfcBGroup& G = g.grp[blockIdx.y];
   switch (G.d1) {
-    case 1: b_block<1, MAXD>(g, G, sfc_lds); break;
-    case 3: b_block<3, MAXD>(g, G, sfc_lds); break;
-    case 5: b_block<(MAXD >= 5 ? 5 : 1), MAXD>(g, G, sfc_lds); break;
-    default: b_block<(MAXD >= 7 ? 7 : 1), MAXD>(g, G, sfc_lds); break;
+    case 1:
+      if (G.nch == 4) b_block<1, 4, MAXD>(g, G, sfc_lds);
+      else if (G.nch == 2) b_block<1, 2, MAXD>(g, G, sfc_lds);
+      else b_block<1, 1, MAXD>(g, G, sfc_lds);
+      break;
+    case 3:
+      if (G.nch == 2) b_block<3, 2, MAXD>(g, G, sfc_lds);
+      else b_block<3, 1, MAXD>(g, G, sfc_lds);
+      break;
+    case 5: b_block<(MAXD >= 5 ? 5 : 1), 1, MAXD>(g, G, sfc_lds); break;
+    default: b_block<(MAXD >= 7 ? 7 : 1), 1, MAXD>(g, G, sfc_lds); break;
   }
 }
 
@@ -764,6 +859,13 @@ double sfc_bytes(const SfcCommon& C) {  // x, w, coupling in; out rows out; weig
 }  // namespace
 
 extern "C" {
+
+/* development aid (not declared in the public header): 8 x u64 device counters the data-gradient kernel adds its
+ * per-phase cycle counts to; NULL disables */
+int eqf_sfc_debug_buffer(void* p) {
+  g_sfc_dbg = (unsigned long long*)p;
+  return 0;
+}
 
 int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
                 const float* const* Wl, const float* bias0, float* out1, const eqf_irreps* out1_irreps, float* out2,
@@ -864,10 +966,13 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
       }
     }
     if (A.nitem == 0) continue;
-    int z = eqf_cdiv(1024, A.nitem);
+    // few, long-running workgroups: every workgroup ends with 32 x 32 x CTT atomics, and the wide kernels run at one
+    // workgroup per CU
+    const int target = cls >= 8 ? 512 : (cls == 4 ? 768 : 1024);
+    int z = eqf_cdiv(target, A.nitem);
     int echunk = eqf_cdiv(E, z);
     echunk = ((echunk + 7) / 8) * 8;
-    if (echunk < 64) echunk = 64;
+    if (echunk < 256) echunk = 256;
     A.echunk = echunk;
     z = eqf_cdiv(E, echunk);
     dim3 grid(z, A.nitem);
@@ -903,6 +1008,7 @@ int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, cons
   if (rc) return rc;
   if (E <= 0) return 0;
   A.dx = dx, A.dw = (w ? dw : nullptr), A.dM = d_coupling;
+  A.dbg = g_sfc_dbg;
   // groups = (input segment, 32-channel chunk); paths sorted by output degree so that a staged d_out tile is shared
   A.ngrp = 0;
   int d3max = 1, mtmax = 0;
@@ -926,10 +1032,15 @@ int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, cons
       nseg++;
     }
   }
-  for (int s = 0; s < nseg; ++s)
-    for (int c = 0; c < seg_mul[s]; c += 32) {
+  for (int s = 0; s < nseg; ++s) {
+    const int d1s = 2 * seg_l[s] + 1;
+    const int nchunks = seg_mul[s] / 32;
+    int cgsz = d1s == 1 ? 4 : (d1s == 3 ? 2 : 1);  // chunks per workgroup: cgsz * d1 <= 6 (register budget of xv / gx)
+    while (nchunks % cgsz != 0) cgsz >>= 1;
+    for (int c = 0; c < seg_mul[s]; c += 32 * cgsz) {
       if (A.ngrp >= B_MAXGRP) return EQF_E_UNSUPPORTED;
       SfcBGroup& G = A.grp[A.ngrp];
+      G.nch = (short)cgsz, G.pad0 = 0;
       G.x_off = seg_off[s] + c;
       G.x_mul = (short)seg_mul[s];
       G.d1 = (short)(2 * seg_l[s] + 1);
@@ -953,6 +1064,7 @@ int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, cons
       if (mt > mtmax) mtmax = mt;
       if (G.npath > 0) A.ngrp++;
     }
+  }
   A.full_m = P->m_numel <= 192;  // 32 whole coupling rows <= 24 KB of LDS
   if (A.full_m) {
     mtmax = P->m_numel;

@@ -56,6 +56,16 @@ def run(name, irr, sh_irr, out_irr, n2, use_w):
     b = lambda: call("eqf_sfc_bwd_data", P(x), P(M), P(w), table.c_ref, Wl, P(d1), lay.c_ref, P(d2), n2, P(dx), P(dw),
                      None, E, st())
     wg = lambda: call("eqf_sfc_bwd_weight", P(x), P(M), P(w), table.c_ref, P(d1), lay.c_ref, P(d2), n2, dWl, E, st())
+    from equiformer_amd import lib as _lib
+    dbg = torch.zeros(8, dtype=torch.int64, device=dev)
+    _lib.load().eqf_sfc_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
+    b()
+    torch.cuda.synchronize()
+    _lib.load().eqf_sfc_debug_buffer(None)
+    d = dbg.cpu().tolist()
+    nb = ((E + 31) // 32)
+    print("%-10s bwd_data phase cycles per workgroup-row (sum over groups / edge tiles): prologue %.0f staging %.0f mfma %.0f "
+          "epilogue %.0f store %.0f" % ((name,) + tuple(v / nb for v in d[:5])), flush=True)
     for tag, fn in (("fwd", f), ("bwd_data", b), ("bwd_weight", wg)):
         us = timeit(fn)
         print("%-10s %-10s E=%d  %8.1f us  %6.1f TFLOP/s  (%.2f GFLOP)" % (name, tag, E, us, flops / us / 1e6, flops / 1e9),
