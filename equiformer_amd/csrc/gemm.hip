@@ -229,8 +229,22 @@ struct RowsArgs {
 enum { A_MEM = 0, A_DTP = 1 };
 enum { B_KN = 0, B_NK = 1 };
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
-__global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
+struct RowsP {  // one problem of a grouped launch (A operand from memory)
+  Rows A, B, C;
+  const float* bias;
+  int M, N, K;
+  int rows_per_tile;
+  int accumulate;
+  int vecA, vecB;
+};
+constexpr int MAX_GROUP = 4;
+struct RowsGroup {
+  int n;
+  RowsP p[MAX_GROUP];
+};
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, class ArgsT>
+__device__ __forceinline__ void gemm_rows_body(const ArgsT& g, const int bx, const int by) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
   constexpr int SA = BM + 1;
@@ -239,8 +253,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
   __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
   __shared__ __attribute__((aligned(16))) float Mt[(AMODE == A_DTP) ? MAX_MTILE : 4];
 
-  const int m0 = blockIdx.x * g.rows_per_tile;
-  const int n0 = blockIdx.y * BN;
+  const int m0 = bx * g.rows_per_tile;
+  const int n0 = by * BN;
   const int mcnt = min(g.rows_per_tile, g.M - m0);
   const int ncnt = min(BN, g.N - n0);
   const int wave = threadIdx.x >> 6;
@@ -259,8 +273,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
   LoaderNatural<BN, SB> lbn;
   LoaderContigK<BN, SB> lbk;
   int e0 = 0, ecnt = 0;
-  if (AMODE == A_DTP) {
-    e0 = blockIdx.x * g.dtp.ept;
+  if constexpr (AMODE == A_DTP) {
+    e0 = bx * g.dtp.ept;
     ecnt = mcnt / g.dtp.d3;
     stage_coupling(Mt, g.dtp, e0, ecnt);
     ld.issue(g.dtp, 0, e0, ecnt);
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
   if (AMODE == A_DTP) __syncthreads();  // coupling tile visible
 
   for (int k0 = 0; k0 < g.K; k0 += BK) {
-    if (AMODE == A_DTP)
+    if constexpr (AMODE == A_DTP)
       ld.commit(As, Mt, g.dtp.m_len, g.dtp.d3, ecnt, 1, SA, 0);
     else
       la.commit(As);
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
     __syncthreads();
     const int k1 = k0 + BK;
     if (k1 < g.K) {
-      if (AMODE == A_DTP)
+      if constexpr (AMODE == A_DTP)
         ld.issue(g.dtp, k1 / BK, e0, ecnt);
       else
         la.issue(g.A, m0, mcnt, k1, g.K, g.vecA);
@@ -320,6 +334,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
     }
 }
 
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(NTHREADS) void gemm_rows_kernel(const RowsArgs g) {
+  gemm_rows_body<BM, BN, WM, WN, AMODE, BMODE>(g, blockIdx.x, blockIdx.y);
+}
+
+// up to MAX_GROUP independent problems (the per-degree GEMMs of one irreps linear) in ONE launch: blockIdx.z picks the
+// problem; the node-level linears are launch / latency bound (2304 rows), so 3-4x fewer launches and 3-4x more
+// workgroups in flight per launch is what matters for them
+template <int BM, int BN, int WM, int WN, int BMODE>
+__global__ __launch_bounds__(NTHREADS) void gemm_rows_group_kernel(const RowsGroup g) {
+  const RowsP& P = g.p[blockIdx.z];
+  if ((int)blockIdx.x * P.rows_per_tile >= P.M || (int)blockIdx.y * BN >= P.N) return;
+  gemm_rows_body<BM, BN, WM, WN, A_MEM, BMODE>(P, blockIdx.x, blockIdx.y);
+}
+
 // ------------------------------------------------------------------------------------------------
 // tn kernel (weight gradients): C[m,n] += sum_rows A[row,m] B[row,n]
 // ------------------------------------------------------------------------------------------------
@@ -334,8 +363,22 @@ struct TnArgs {
   DtpA dtp;
 };
 
-template <int BM, int BN, int WM, int WN, int WK, int AMODE>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
+struct TnP {  // one problem of a grouped launch (A operand from memory)
+  Rows A, B;
+  float* C;
+  int ldc;
+  int M, N, R;
+  int rows_per_step;
+  int steps_per_split;
+  int vecA, vecB;
+};
+struct TnGroup {
+  int n;
+  TnP p[MAX_GROUP];
+};
+
+template <int BM, int BN, int WM, int WN, int WK, int AMODE, class ArgsT>
+__device__ __forceinline__ void gemm_tn_body(const ArgsT& g, const int bx, const int by, const int bz) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN * WK == 4 && TM >= 1 && TN >= 1, "4 waves");
   constexpr int SA = BM + 4, SB = BN + 4;
@@ -343,7 +386,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BK * SA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
 
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = bx * BM, n0 = by * BN;
   const int wave = threadIdx.x >> 6;
   const int wk = wave % WK;
   const int wmn = wave / WK;
@@ -358,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   const int total_steps = (g.R + g.rows_per_step - 1) / g.rows_per_step;
-  const int s_beg = blockIdx.z * g.steps_per_split;
+  const int s_beg = bz * g.steps_per_split;
   const int s_end = min(total_steps, s_beg + g.steps_per_split);
   const int nslab = min(BM, g.M - m0) / 32;
 
@@ -370,7 +413,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
   auto issue = [&](int s) {
     const int r0 = s * g.rows_per_step;
     const int rcnt = min(g.rows_per_step, g.R - r0);
-    if (AMODE == A_MEM) {
+    if constexpr (AMODE == A_MEM) {
       la.issue(g.A, r0, rcnt, m0, g.M, g.vecA);
     } else {
 #pragma unroll
@@ -380,7 +423,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
     lb.issue(g.B, r0, rcnt, n0, g.N, g.vecB);
   };
 
-  if (AMODE == A_DTP) {
+  if constexpr (AMODE == A_DTP) {
     for (int i = threadIdx.x; i < BK * SA; i += NTHREADS) As[i] = 0.f;  // padding rows / absent slabs stay zero
     __syncthreads();
   }
@@ -388,7 +431,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
   for (int s = s_beg; s < s_end; ++s) {
     const int r0 = s * g.rows_per_step;
     const int rcnt = min(g.rows_per_step, g.R - r0);
-    if (AMODE == A_MEM) {
+    if constexpr (AMODE == A_MEM) {
       la.commit(As);
     } else {
       const int ecnt = rcnt / g.dtp.d3;
@@ -425,6 +468,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
         if (row < g.M) atomicAdd(g.C + (long)row * g.ldc + col, acc[i][j][q]);
       }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int WK, int AMODE>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const TnArgs g) {
+  gemm_tn_body<BM, BN, WM, WN, WK, AMODE>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// grouped weight gradients: grid.z = sum of the problems' split counts; zoff[] maps blockIdx.z to (problem, split)
+struct TnGroupLaunch {
+  TnGroup g;
+  int zoff[MAX_GROUP + 1];
+};
+template <int BM, int BN, int WM, int WN, int WK>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_group_kernel(const TnGroupLaunch L) {
+  int pi = 0;
+  while (pi + 1 < L.g.n && (int)blockIdx.z >= L.zoff[pi + 1]) ++pi;
+  const TnP& P = L.g.p[pi];
+  if ((int)blockIdx.x * BM >= P.M || (int)blockIdx.y * BN >= P.N) return;
+  gemm_tn_body<BM, BN, WM, WN, WK, A_MEM>(P, blockIdx.x, blockIdx.y, (int)blockIdx.z - L.zoff[pi]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -608,6 +670,99 @@ int eqf_gemm_tn(const float* A, eqf_rows ra, const float* B, eqf_rows rb, float*
   a.vecA = rows_vec_ok(A, ra);
   a.vecB = rows_vec_ok(B, rb);
   return launch_tn<A_MEM>(a, (hipStream_t)stream);
+}
+
+int eqf_gemm_group(const eqf_gemm_desc* d, int n, void* stream) {
+  if (!d || n < 1 || n > MAX_GROUP) return EQF_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  // rows problems (kind 0: C = A B, kind 1: C = A B^T) share one launch per kind; tn problems (kind 2) another
+  for (int kind = 0; kind < 2; ++kind) {
+    RowsGroup G{};
+    int maxm = 0, maxn = 0, bn_need = 32;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      if (d[i].kind != kind) continue;
+      if (!d[i].A || !d[i].B || !d[i].C || d[i].ra.d < 1 || d[i].rc.d < 1) return EQF_E_BADARG;
+      if (d[i].M <= 0 || d[i].N <= 0) continue;
+      RowsP& P = G.p[G.n++];
+      P.A = {d[i].A, d[i].ra.d, d[i].ra.ld, d[i].ra.inner};
+      P.B = {d[i].B, 1, d[i].ldb, 0};
+      P.C = {d[i].C, d[i].rc.d, d[i].rc.ld, d[i].rc.inner};
+      P.bias = d[i].bias;
+      P.M = d[i].M, P.N = d[i].N, P.K = d[i].K, P.accumulate = d[i].accumulate;
+      P.vecA = rows_vec_ok(d[i].A, d[i].ra);
+      P.vecB = aligned16(d[i].B) && d[i].ldb % 4 == 0;
+      P.rows_per_tile = 64;
+      if (P.N > 32) bn_need = 64;
+      flops += 2.0 * P.M * (double)P.N * P.K;
+      bytes += 4.0 * ((double)P.M * P.K + (double)P.K * P.N + (double)P.M * P.N);
+    }
+    if (G.n == 0) continue;
+    const int rpt = bn_need == 64 ? 64 : 128;
+    for (int i = 0; i < G.n; ++i) {
+      G.p[i].rows_per_tile = rpt;
+      const int tm = eqf_cdiv(G.p[i].M, rpt), tn = eqf_cdiv(G.p[i].N, bn_need);
+      if (tm > maxm) maxm = tm;
+      if (tn > maxn) maxn = tn;
+    }
+    dim3 grid(maxm, maxn, G.n);
+    const int pid = eqf_prof_begin(kind == 0 ? "gemm_group_kn" : "gemm_group_nk", st, flops, bytes);
+    if (kind == 0) {
+      if (bn_need == 64)
+        hipLaunchKernelGGL((gemm_rows_group_kernel<64, 64, 2, 2, B_KN>), grid, dim3(NTHREADS), 0, st, G);
+      else
+        hipLaunchKernelGGL((gemm_rows_group_kernel<128, 32, 4, 1, B_KN>), grid, dim3(NTHREADS), 0, st, G);
+    } else {
+      if (bn_need == 64)
+        hipLaunchKernelGGL((gemm_rows_group_kernel<64, 64, 2, 2, B_NK>), grid, dim3(NTHREADS), 0, st, G);
+      else
+        hipLaunchKernelGGL((gemm_rows_group_kernel<128, 32, 4, 1, B_NK>), grid, dim3(NTHREADS), 0, st, G);
+    }
+    eqf_prof_end(pid, st);
+    EQF_CHECK_LAUNCH();
+  }
+  {
+    TnGroupLaunch L{};
+    int maxm = 0, maxn = 0, z = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      if (d[i].kind != 2) continue;
+      if (!d[i].A || !d[i].B || !d[i].C || d[i].ra.d < 1 || d[i].rc.d < 1) return EQF_E_BADARG;
+      if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0) continue;
+      // kind 2:  C[M,N] (plain, leading dimension ldb) += sum over K rows of A[row, 0:M]^T B'[row, 0:N], B' given as (C-field rows rc)
+      TnP& P = L.g.p[L.g.n];
+      P.A = {d[i].A, d[i].ra.d, d[i].ra.ld, d[i].ra.inner};
+      P.B = {d[i].B, d[i].rc.d, d[i].rc.ld, d[i].rc.inner};
+      P.C = d[i].C, P.ldc = d[i].ldb, P.M = d[i].M, P.N = d[i].N, P.R = d[i].K;
+      P.rows_per_step = BK;
+      P.vecA = rows_vec_ok(d[i].A, d[i].ra);
+      P.vecB = rows_vec_ok(d[i].B, d[i].rc);
+      const int tiles = eqf_cdiv(P.M, 64) * eqf_cdiv(P.N, 64);
+      const int total_steps = eqf_cdiv(P.R, BK);
+      int ksplit = 1024 / (tiles > 0 ? tiles : 1);
+      const int max_split = eqf_cdiv(total_steps, 8);
+      if (ksplit > max_split) ksplit = max_split;
+      if (ksplit < 1) ksplit = 1;
+      P.steps_per_split = eqf_cdiv(total_steps, ksplit);
+      ksplit = eqf_cdiv(total_steps, P.steps_per_split);
+      L.zoff[L.g.n] = z;
+      z += ksplit;
+      L.g.n++;
+      if (eqf_cdiv(P.M, 64) > maxm) maxm = eqf_cdiv(P.M, 64);
+      if (eqf_cdiv(P.N, 64) > maxn) maxn = eqf_cdiv(P.N, 64);
+      flops += 2.0 * P.M * (double)P.N * P.R;
+      bytes += 4.0 * ((double)P.R * P.M + (double)P.R * P.N + (double)P.M * P.N);
+    }
+    if (L.g.n > 0) {
+      L.zoff[L.g.n] = z;
+      dim3 grid(maxm, maxn, z);
+      const int pid = eqf_prof_begin("gemm_group_tn", st, flops, bytes);
+      hipLaunchKernelGGL((gemm_tn_group_kernel<64, 64, 2, 2, 1>), grid, dim3(NTHREADS), 0, st, L);
+      eqf_prof_end(pid, st);
+      EQF_CHECK_LAUNCH();
+    }
+  }
+  return 0;
 }
 
 int eqf_dtp_linear_fwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,

@@ -49,8 +49,10 @@ struct SfcSlab {
 };
 
 struct SfcDeg {
-  const float* W;  // [K, Ncat] row-major
-  float* dW;       // weight-gradient target (same shape), accumulated
+  const float* W;   // [K, N1] row-major: main consumer
+  const float* W2;  // [K, N2] row-major: second scalar consumer (degree 0 only), may be null
+  float* dW;        // weight-gradient targets (same shapes), accumulated
+  float* dW2;
   int l3, d3, K, N1, N2, Ncat;
   int out1_off;    // offset of the degree segment inside an out1 row
   int m_base, m_len;  // block of the coupling row holding the matrices of all paths into l3
@@ -94,7 +96,8 @@ struct IC {
 
 struct SfcFwdArgs {
   SfcCommon c;
-  const float* bias;  // [Ncat of degree 0] or null
+  const float* bias;   // [N1 of degree 0] or null
+  const float* bias2;  // [N2] or null
   int nsplit[SFC_MAX_DEG], cps[SFC_MAX_DEG], blk0[SFC_MAX_DEG + 1];
 };
 
@@ -217,9 +220,13 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     }
     // column blocks beyond CT re-read the last valid block (their LDS columns are never used): no guards, no
     // dynamic indexing of bv
-    const float* wp = D.W + (long)(s * 32 + (t >> 3)) * D.Ncat + ncol0 + 4 * (t & 7);
+    const int wk = s * 32 + (t >> 3);  // row of the weight matrices
 #pragma unroll
-    for (int j = 0; j < CTCAP; ++j) bv[j] = *reinterpret_cast<const f32x4*>(wp + 32 * (j < CT ? j : CT - 1));
+    for (int j = 0; j < CTCAP; ++j) {
+      const int c = ncol0 + 32 * (j < CT ? j : CT - 1);  // 32-column block: entirely main or entirely second consumer
+      const float* wp = (c < D.N1) ? D.W + (long)wk * D.N1 + c : D.W2 + (long)wk * D.N2 + (c - D.N1);
+      bv[j] = *reinterpret_cast<const f32x4*>(wp + 4 * (t & 7));
+    }
   };
   const int awb = AS0 + u * SA + grp;
   const int mrow = MT0 + grp * m_len;
@@ -273,7 +280,11 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
   for (int i = 0; i < FT; ++i) {
     if (i >= ntw) continue;
     const int c = ncol0 + boff[i] + r;
-    const float bvl = (g.bias && D.l3 == 0) ? g.bias[c] : 0.f;
+    float bvl = 0.f;
+    if (D.l3 == 0) {
+      if (c < D.N1) bvl = g.bias ? g.bias[c] : 0.f;
+      else bvl = g.bias2 ? g.bias2[c - D.N1] : 0.f;
+    }
     float* base;
     long ld;
     int coff, mstride;
@@ -483,11 +494,13 @@ __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
 #pragma unroll
   for (int ct = 0; ct < CTT; ++ct)
     if (ct < CT) {
-      const int c = col0 + ct * 32 + r;
+      const int c0 = col0 + ct * 32;  // a 32-column tile lies entirely in one of the two weight matrices (uniform select)
+      float* base = (c0 < D.N1) ? D.dW + c0 : D.dW2 + (c0 - D.N1);
+      const int ldw = (c0 < D.N1) ? D.N1 : D.N2;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int ch = slab_in_deg * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;
-        atomicAdd(D.dW + (long)ch * D.Ncat + c, acc[ct][q]);
+        atomicAdd(base + ch * ldw + r, acc[ct][q]);
       }
     }
 }
@@ -612,10 +625,18 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
       for (int ck = 0; ck < nchunk; ++ck) {
         const int kc0 = ck * B_KC, kcn = min(B_KC, Ncat - kc0);
         // MFMA k mapping: lane group kg supplies k = kb + 4 kg + jj for the jj-th instruction of a 16-wide k block
-        const float* wrow = D.W + (long)(P.krow + 32 * c + ch) * Ncat + kc0 + 4 * kg;
-        // weight fragments of the first two k blocks (kcn is a multiple of 32): in flight across the staging below
-        f32x4 bA = *reinterpret_cast<const f32x4*>(wrow);
-        f32x4 bB = *reinterpret_cast<const f32x4*>(wrow + 16);
+        // weight fragment of the 16-wide k block starting at column kk of the concatenated [main | second] weight
+        // The columns [kc0, kc0+kcn) of the concatenated [main | second] weight split into at most two segments with
+        // ONE row pointer each (a per-load pointer select costs ~18 % in this issue-bound loop).
+        const long wr = P.krow + 32 * c + ch;
+        const float* w1row = D.W + wr * N1 + 4 * kg;
+        const float* w2row = D.W2 ? D.W2 + wr * D.N2 - N1 + 4 * kg : nullptr;
+        const int ks = min(max(N1 - kc0, 0), kcn);  // columns [0, ks) of the chunk come from W, [ks, kcn) from W2
+        const float* rowA = (ks > 0) ? w1row : w2row;
+        const int endA = (ks > 0) ? ks : kcn;
+        // fragments of the first two k blocks (segment lengths are multiples of 32): in flight across the staging
+        f32x4 bA = *reinterpret_cast<const f32x4*>(rowA + kc0);
+        f32x4 bB = *reinterpret_cast<const f32x4*>(rowA + kc0 + 16);
         if (!(nchunk == 1 && staged_deg == P.deg)) {
           __syncthreads();  // readers of the previous Dt contents are done
           // stage Dt[k][row] = d_out[e0 + el, m3, kc0 + k],  row = m3*32 + el.  A wave step covers 16 float4 columns x
@@ -660,36 +681,46 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
         // Two k blocks per iteration with statically named ping-pong registers (no register rotation, no copies): the
         // LDS operands (aA / aB) and the weight fragments (bA / bB) of a block are requested one block / two blocks
         // before its MFMAs are issued.
-        float aA[4][D3], aB[4][D3];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-          for (int rt = 0; rt < D3; ++rt) aA[jj][rt] = ap[jj * SD + rt * 32];
-#pragma unroll 1
-        for (int kb = 0; kb < kcn; kb += 32) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int rt = 0; rt < D3; ++rt) aB[jj][rt] = ap[(16 + jj) * SD + rt * 32];
-          const f32x4 b0 = bA;
-          bA = *reinterpret_cast<const f32x4*>(wrow + (kb + 32 < kcn ? kb + 32 : 0));
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int rt = 0; rt < D3; ++rt)
-              acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[jj][rt], b0[jj], acc[jj & 1][rt], 0, 0, 0);
-          ap += (kb + 32 < kcn) ? 32 * SD : 0;  // the last iteration re-reads its own first block (harmless)
+        auto seg = [&](const int kb0, const int kb1, const float* rowp) __attribute__((always_inline)) {
+          float aA[4][D3], aB[4][D3];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int rt = 0; rt < D3; ++rt) aA[jj][rt] = ap[jj * SD + rt * 32];
-          const f32x4 b1 = bB;
-          bB = *reinterpret_cast<const f32x4*>(wrow + (kb + 48 < kcn ? kb + 48 : 0));
+          const float* wp = rowp + kc0;
+#pragma unroll 1
+          for (int kb = kb0; kb < kb1; kb += 32) {
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int rt = 0; rt < D3; ++rt)
-              acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[jj][rt], b1[jj], acc[jj & 1][rt], 0, 0, 0);
+              for (int rt = 0; rt < D3; ++rt) aB[jj][rt] = ap[(16 + jj) * SD + rt * 32];
+            const f32x4 b0 = bA;
+            bA = *reinterpret_cast<const f32x4*>(wp + (kb + 32 < kb1 ? kb + 32 : kb0));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+              for (int rt = 0; rt < D3; ++rt)
+                acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[jj][rt], b0[jj], acc[jj & 1][rt], 0, 0, 0);
+            ap += 32 * SD;  // after the last block of the chunk this points past the tile: the reads below are then
+                            // of in-bounds LDS garbage that is never used
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+              for (int rt = 0; rt < D3; ++rt) aA[jj][rt] = ap[jj * SD + rt * 32];
+            const f32x4 b1 = bB;
+            bB = *reinterpret_cast<const f32x4*>(wp + (kb + 48 < kb1 ? kb + 48 : kb0));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+              for (int rt = 0; rt < D3; ++rt)
+                acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[jj][rt], b1[jj], acc[jj & 1][rt], 0, 0, 0);
+          }
+        };
+        seg(0, endA, rowA);
+        if (endA < kcn) {
+          bA = *reinterpret_cast<const f32x4*>(w2row + kc0 + endA);
+          bB = *reinterpret_cast<const f32x4*>(w2row + kc0 + endA + 16);
+          seg(endA, kcn, w2row);
         }
       }
       tick(2);  // MFMA loop
@@ -755,19 +786,17 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
   tick(4);  // dx stores
 }
 
+// One launch covers every (input degree, chunk group) flavour: the flavours have different costs, and a single large
+// grid packs the CUs much better than one launch per flavour (measured: 3 launches of 793 workgroups were 25 % slower).
 template <int MAXD>
 __global__ __launch_bounds__(256, (MAXD <= 5 ? 2 : 1)) void sfc_bwd_kernel(const SfcBwdArgs g) {
   const SfcBGroup& G = g.grp[blockIdx.y];
   switch (G.d1) {
     case 1:
-      if (G.nch == 4) b_block<1, 4, MAXD>(g, G, sfc_lds);
-      else if (G.nch == 2) b_block<1, 2, MAXD>(g, G, sfc_lds);
+      if (G.nch == 2) b_block<1, 2, MAXD>(g, G, sfc_lds);
       else b_block<1, 1, MAXD>(g, G, sfc_lds);
       break;
-    case 3:
-      if (G.nch == 2) b_block<3, 2, MAXD>(g, G, sfc_lds);
-      else b_block<3, 1, MAXD>(g, G, sfc_lds);
-      break;
+    case 3: b_block<3, 1, MAXD>(g, G, sfc_lds); break;
     case 5: b_block<(MAXD >= 5 ? 5 : 1), 1, MAXD>(g, G, sfc_lds); break;
     default: b_block<(MAXD >= 7 ? 7 : 1), 1, MAXD>(g, G, sfc_lds); break;
   }
@@ -776,8 +805,8 @@ __global__ __launch_bounds__(256, (MAXD <= 5 ? 2 : 1)) void sfc_bwd_kernel(const
 // ------------------------------------------------------------------------------------------------ host side
 // Fill the degree / slab tables.  o1_irreps: one segment per output degree; n2 extra scalar columns on degree 0.
 int build_common(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* P,
-                 const float* const* Wl, float* const* dWl, float* o1, const eqf_irreps* o1_irreps, float* o2, int n2,
-                 int E, SfcCommon& C) {
+                 const float* const* Wl, const float* W2, float* const* dWl, float* dW2, float* o1,
+                 const eqf_irreps* o1_irreps, float* o2, int n2, int E, SfcCommon& C) {
   if (!x || !coupling || !P || !o1 || !o1_irreps) return EQF_E_BADARG;
   if (o1_irreps->nseg < 1 || o1_irreps->nseg > SFC_MAX_DEG || P->npaths < 1 || P->npaths > EQF_MAX_PATHS)
     return EQF_E_BADARG;
@@ -802,6 +831,8 @@ int build_common(const float* x, const float* coupling, const float* w, const eq
     if (D.l3 > 3 || D.Ncat % 32 != 0 || D.N1 % 32 != 0) return EQF_E_UNSUPPORTED;
     D.W = Wl ? Wl[D.l3] : nullptr;
     D.dW = dWl ? dWl[D.l3] : nullptr;
+    D.W2 = (D.l3 == 0) ? W2 : nullptr;
+    D.dW2 = (D.l3 == 0) ? dW2 : nullptr;
     int K = 0, m_lo = 1 << 30, m_hi = 0;
     for (int p = 0; p < P->npaths; ++p)
       if (P->l3[p] == D.l3) {
@@ -868,14 +899,15 @@ int eqf_sfc_debug_buffer(void* p) {
 }
 
 int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
-                const float* const* Wl, const float* bias0, float* out1, const eqf_irreps* out1_irreps, float* out2,
-                int n2, int E, void* stream) {
-  if (!Wl) return EQF_E_BADARG;
+                const float* const* Wl, const float* bias0, const float* W2, const float* bias2, float* out1,
+                const eqf_irreps* out1_irreps, float* out2, int n2, int E, void* stream) {
+  if (!Wl || (n2 > 0 && !W2)) return EQF_E_BADARG;
   SfcFwdArgs A;
-  int rc = build_common(x, coupling, w, paths, Wl, nullptr, out1, out1_irreps, out2, n2, E, A.c);
+  int rc = build_common(x, coupling, w, paths, Wl, W2, nullptr, nullptr, out1, out1_irreps, out2, n2, E, A.c);
   if (rc) return rc;
   if (E <= 0) return 0;
   A.bias = bias0;
+  A.bias2 = bias2;
   int md = max_d1(A.c);
   for (int d = 0; d < A.c.ndeg; ++d) md = A.c.deg[d].d3 > md ? A.c.deg[d].d3 : md;
   const int ft = md <= 5 ? 3 : F_MAXT;
@@ -925,10 +957,10 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
 
 int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
                        const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2, int n2,
-                       float* const* dWl, int E, void* stream) {
-  if (!dWl) return EQF_E_BADARG;
+                       float* const* dWl, float* dW2, int E, void* stream) {
+  if (!dWl || (n2 > 0 && !dW2)) return EQF_E_BADARG;
   SfcWgArgs A;
-  int rc = build_common(x, coupling, w, paths, nullptr, dWl, const_cast<float*>(d_out1), out1_irreps,
+  int rc = build_common(x, coupling, w, paths, nullptr, nullptr, dWl, dW2, const_cast<float*>(d_out1), out1_irreps,
                         const_cast<float*>(d_out2), n2, E, A.c);
   if (rc) return rc;
   if (E <= 0) return 0;
@@ -999,11 +1031,11 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
 }
 
 int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
-                     const float* const* Wl, const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2,
-                     int n2, float* dx, float* dw, float* d_coupling, int E, void* stream) {
-  if (!Wl || !dx) return EQF_E_BADARG;
+                     const float* const* Wl, const float* W2, const float* d_out1, const eqf_irreps* out1_irreps,
+                     const float* d_out2, int n2, float* dx, float* dw, float* d_coupling, int E, void* stream) {
+  if (!Wl || !dx || (n2 > 0 && !W2)) return EQF_E_BADARG;
   SfcBwdArgs A;
-  int rc = build_common(x, coupling, w, paths, Wl, nullptr, const_cast<float*>(d_out1), out1_irreps,
+  int rc = build_common(x, coupling, w, paths, Wl, W2, nullptr, nullptr, const_cast<float*>(d_out1), out1_irreps,
                         const_cast<float*>(d_out2), n2, E, A.c);
   if (rc) return rc;
   if (E <= 0) return 0;
@@ -1035,7 +1067,7 @@ int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, cons
   for (int s = 0; s < nseg; ++s) {
     const int d1s = 2 * seg_l[s] + 1;
     const int nchunks = seg_mul[s] / 32;
-    int cgsz = d1s == 1 ? 4 : (d1s == 3 ? 2 : 1);  // chunks per workgroup: cgsz * d1 <= 6 (register budget of xv / gx)
+    int cgsz = d1s == 1 ? 2 : 1;  // chunks per workgroup (register budget: more chunks per workgroup spill)
     while (nchunks % cgsz != 0) cgsz >>= 1;
     for (int c = 0; c < seg_mul[s]; c += 32 * cgsz) {
       if (A.ngrp >= B_MAXGRP) return EQF_E_UNSUPPORTED;

@@ -25,6 +25,11 @@ class EqfRows(ctypes.Structure):
     _fields_ = [("d", c_int), ("ld", c_int), ("inner", c_int)]
 
 
+class EqfGemmDesc(ctypes.Structure):
+    _fields_ = [("A", c_fp), ("B", c_fp), ("C", c_fp), ("bias", c_fp), ("ra", EqfRows), ("rc", EqfRows),
+                ("ldb", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("accumulate", c_int), ("kind", c_int)]
+
+
 _PA = c_int * EQF_MAX_PATHS
 
 
@@ -54,14 +59,15 @@ SIGNATURES = {
     "eqf_gemm_nn": [c_fp, EqfRows, c_fp, c_int, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
     "eqf_gemm_nt": [c_fp, EqfRows, c_fp, c_int, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
     "eqf_gemm_tn": [c_fp, EqfRows, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
+    "eqf_gemm_group": [ctypes.POINTER(EqfGemmDesc), c_int, c_fp],
     "eqf_colsum": [c_fp, EqfRows, c_int, c_int, c_fp, c_fp],
     "eqf_dtp_coupling_fwd": [c_fp, c_fp, _P_PATHS, c_fp, c_int, c_fp],
     "eqf_dtp_coupling_bwd": [c_fp, c_fp, _P_PATHS, c_fp, c_int, c_fp],
     "eqf_dtp_linear_fwd": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, _P_IRR, c_int, c_fp],
     "eqf_dtp_linear_wgrad": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, _PP, c_int, c_fp],
-    "eqf_sfc_fwd": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, _P_IRR, c_fp, c_int, c_int, c_fp],
-    "eqf_sfc_bwd_data": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, _P_IRR, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp],
-    "eqf_sfc_bwd_weight": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, c_fp, c_int, _PP, c_int, c_fp],
+    "eqf_sfc_fwd": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, c_fp, c_fp, _P_IRR, c_fp, c_int, c_int, c_fp],
+    "eqf_sfc_bwd_data": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, _P_IRR, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp],
+    "eqf_sfc_bwd_weight": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, c_fp, c_int, _PP, c_fp, c_int, c_fp],
     "eqf_layernorm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, _f, c_fp],
     "eqf_layernorm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, c_fp],
     "eqf_gate_fwd": [c_fp, c_fp, c_int, c_int, _P_IRR, _f, _f, c_fp],

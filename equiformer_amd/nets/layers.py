@@ -320,6 +320,13 @@ class SeparableFCTP(nn.Module):
                     if p["l3"] == l3:
                         idx.extend(range(p["w_off"], p["w_off"] + p["mul"]))
             self.register_buffer("_row_to_w", torch.tensor(idx, dtype=torch.long), persistent=False)
+            # element of the flat lin weight -> index of the shared DTP weight scaling its row
+            elem, r = [], 0
+            for (l, _, K, _, N, w_off) in self.lin.spec.pairs:
+                for k in range(K):
+                    elem.extend([idx[r + k]] * N)
+                r += K
+            self.register_buffer("_elem_to_w", torch.tensor(elem, dtype=torch.long), persistent=False)
 
     def folded_lin_weight(self):
         """lin weight with the shared depth-wise weights folded into its rows:
@@ -332,18 +339,12 @@ class SeparableFCTP(nn.Module):
             r += K
         return torch.cat(chunks)
 
-    def degree_weights(self):
-        """[K(l), N(l)] views of the flat lin weight, one per output degree (ascending); the shared depth-wise weights
-        (internal_weights=True) are folded into the rows."""
-        Ws, r = [], 0
-        scale = self.dtp.tp.weight[self._row_to_w] if self.dtp.tp.internal_weights else None
-        for (l, _, K, _, N, w_off) in self.lin.spec.pairs:
-            W = self.lin.tp.weight[w_off:w_off + K * N].view(K, N)
-            if scale is not None:
-                W = W * scale[r:r + K, None]
-            Ws.append(W)
-            r += K
-        return Ws
+    def flat_weight(self):
+        """Flat lin weight ([K(l), N(l)] blocks, ascending degree) with the shared depth-wise weights
+        (internal_weights=True) folded into the rows: two element-wise kernels instead of per-degree slicing."""
+        if self.dtp.tp.internal_weights:
+            return self.lin.tp.weight * self.dtp.tp.weight[self._elem_to_w]
+        return self.lin.tp.weight
 
     def forward(self, node_input, ectx, use_fused=True):
         table = self.dtp.table
@@ -352,7 +353,7 @@ class SeparableFCTP(nn.Module):
         w = self.dtp_rad(ectx.edge_scalars) if self.dtp_rad is not None else None
         bias = self.lin._bias()
         if use_fused is True and self.sfc_spec.supported:
-            out = ops.sep_fctp(node_input, M, w, bias, self.sfc_spec, self.degree_weights())
+            out = ops.sep_fctp(node_input, M, w, self.flat_weight(), bias, self.sfc_spec)
         elif use_fused and self.fused_spec is not None:
             weight = self.folded_lin_weight() if internal else self.lin.tp.weight
             out = ops.dtp_linear(node_input, M, w, weight, bias, self.fused_spec)
@@ -424,11 +425,8 @@ class GraphAttention(nn.Module):
         M = ectx.coupling(table)
         weight = sa.dtp_rad(ectx.edge_scalars)
         if self.use_fused is True and self.act_sfc_spec.supported:
-            Ws = sa.degree_weights()
-            K0 = Ws[0].shape[0]
-            Ws[0] = torch.cat([Ws[0], self.sep_alpha.tp.weight.view(K0, -1)], dim=1)
-            bias = torch.cat([sa.lin._bias(), self.sep_alpha._bias()])
-            value, alpha = ops.sep_fctp(message, M, weight, bias, self.act_sfc_spec, Ws)
+            value, alpha = ops.sep_fctp(message, M, weight, sa.flat_weight(), sa.lin._bias(), self.act_sfc_spec,
+                                        weight2=self.sep_alpha.tp.weight, bias2=self.sep_alpha._bias())
         elif self.use_fused and sa.fused_spec is not None:
             value = ops.dtp_linear(message, M, weight, sa.lin.tp.weight, sa.lin._bias(), sa.fused_spec)
             alpha = ops.dtp_linear(message, M, weight, self.sep_alpha.tp.weight, self.sep_alpha._bias(),
@@ -557,8 +555,7 @@ class EdgeDegreeEmbeddingNetwork(nn.Module):
         src_features = ops.gather_add(node_features, None, g)
         M = ectx.coupling(self.dw.table)
         if self.use_fused is True and self.sfc_spec.supported:
-            Ws = [self.proj.tp.weight[w_off:w_off + K * N].view(K, N) for (_, _, K, _, N, w_off) in self.proj.spec.pairs]
-            edge_features = ops.sep_fctp(src_features, M, weight, self.proj._bias(), self.sfc_spec, Ws)
+            edge_features = ops.sep_fctp(src_features, M, weight, self.proj.tp.weight, self.proj._bias(), self.sfc_spec)
         elif self.use_fused and self.fused_spec is not None:
             edge_features = ops.dtp_linear(src_features, M, weight, self.proj.tp.weight, self.proj._bias(),
                                            self.fused_spec)

@@ -12,7 +12,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import lib
-from .lib import EqfRows, call
+from .lib import EqfGemmDesc, EqfRows, call
 
 
 class HipOnlyError(RuntimeError):
@@ -116,6 +116,19 @@ class LinearSpec:
         self.fan_in = {l: K for (l, _, K, _, _, _) in self.pairs}
 
 
+def _gemm_group(descs, st):
+    """One launch per kind for up to 4 per-degree GEMMs (eqf_gemm_group)."""
+    for i in range(0, len(descs), 4):
+        chunk = descs[i:i + 4]
+        arr = (EqfGemmDesc * len(chunk))(*chunk)
+        call("eqf_gemm_group", arr, len(chunk), st)
+
+
+def _desc(kind, A, ra, B, ldb, C, rc, bias, M, N, K):
+    return EqfGemmDesc(_p(A[0], A[1]), _p(B[0], B[1]), _p(C[0], C[1]), _p(bias), ra, rc, int(ldb), int(M), int(N), int(K),
+                       0, kind)
+
+
 class _IrrepsLinear(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, spec):
@@ -126,12 +139,13 @@ class _IrrepsLinear(Function):
         Din, Dout = spec.in_layout.dim, spec.out_layout.dim
         assert x.shape[1] == Din and weight.numel() == spec.weight_numel
         out = (torch.empty if spec.out_covered else torch.zeros)((n, Dout), device=x.device, dtype=torch.float32)
-        st = _stream()
+        descs = []
         for (l, in_off, K, out_off, N, w_off) in spec.pairs:
             d = 2 * l + 1
-            b = _p(bias) if (l == 0 and bias is not None) else None
-            call("eqf_gemm_nn", _p(x, in_off), rows(d, Din, K), _p(weight, w_off), N, _p(out, out_off), rows(d, Dout, N),
-                 b, n * d, N, K, 0, st)
+            b = bias if (l == 0 and bias is not None) else None
+            descs.append(_desc(0, (x, in_off), rows(d, Din, K), (weight, w_off), N, (out, out_off), rows(d, Dout, N), b,
+                               n * d, N, K))
+        _gemm_group(descs, _stream())
         ctx.save_for_backward(x, weight)
         ctx.spec = spec
         ctx.has_bias = bias is not None
@@ -148,21 +162,26 @@ class _IrrepsLinear(Function):
         Din, Dout = spec.in_layout.dim, spec.out_layout.dim
         st = _stream()
         dx = dw = db = None
+        descs = []
         if ctx.needs_input_grad[0]:
             dx = (torch.empty if spec.in_covered else torch.zeros)((n, Din), device=x.device, dtype=torch.float32)
             for (l, in_off, K, out_off, N, w_off) in spec.pairs:
                 d = 2 * l + 1
-                call("eqf_gemm_nt", _p(dy, out_off), rows(d, Dout, N), _p(weight, w_off), N, _p(dx, in_off),
-                     rows(d, Din, K), None, n * d, K, N, 0, st)
+                descs.append(_desc(1, (dy, out_off), rows(d, Dout, N), (weight, w_off), N, (dx, in_off), rows(d, Din, K),
+                                   None, n * d, K, N))
+            _gemm_group(descs, st)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
             dw_, db_ = _zeros2(weight.numel(), spec.bias_dim if want_b else 0, x.device)
         if ctx.needs_input_grad[1]:
             dw = dw_
+            descs = []
             for (l, in_off, K, out_off, N, w_off) in spec.pairs:
                 d = 2 * l + 1
-                call("eqf_gemm_tn", _p(x, in_off), rows(d, Din, K), _p(dy, out_off), rows(d, Dout, N), _p(dw, w_off), N,
-                     K, N, n * d, st)
+                # kind 2: C[K,N] += sum_rows x[row, 0:K]^T dy[row, 0:N]; "rc" describes the dy rows, ldb = ldc
+                descs.append(_desc(2, (x, in_off), rows(d, Din, K), (dy, out_off), N, (dw, w_off), rows(d, Dout, N), None,
+                                   K, N, n * d))
+            _gemm_group(descs, st)
         if want_b:
             db = db_
             j = spec.out_layout.seg_index(0)
@@ -659,6 +678,7 @@ class SfcSpec:
     def __init__(self, table, out_layout, n2=0):
         self.table, self.out_layout, self.n2 = table, out_layout, int(n2)
         self.degs = []  # (l3, K, N1, Ncat)
+        self.w_offs = []  # offset of the [K, N1] block of each degree in the flat main weight
         ok = table.fusable
         for (N1, l3) in out_layout.segs:
             i = table.layout_out.seg_index(l3)
@@ -668,6 +688,7 @@ class SfcSpec:
             ncat = N1 + (self.n2 if l3 == 0 else 0)
             ok = ok and ncat % 32 == 0 and N1 % 32 == 0 and l3 <= 3
             self.degs.append((l3, K, N1, ncat))
+            self.w_offs.append(sum(k * n for (_, k, n, _) in self.degs[:-1]))
         if self.n2 and out_layout.seg_index(0) is None:
             ok = False
         # LDS footprint of the forward workgroup (A tile + weight tile + coupling tile of 64 edges), see sfc.hip
@@ -675,6 +696,9 @@ class SfcSpec:
             m_len = sum((2 * p["l1"] + 1) * (2 * l3 + 1) for p in table.paths if p["l3"] == l3)
             ok = ok and 4 * (32 * (64 * (2 * l3 + 1) + 1) + 32 * 68 + 64 * m_len) <= 160 * 1024
         self.supported = ok and len(self.degs) <= 4
+        self.weight_numel = sum(k * n for (_, k, n, _) in self.degs)
+        k0 = [k for (l3, k, _, _) in self.degs if l3 == 0]
+        self.weight2_numel = (k0[0] * self.n2) if (self.n2 and k0) else 0
         self.bias_dim = out_layout.mul_of(0) + self.n2
         used = {l3 for l3, _, _, _ in self.degs}
         self.in_covered = {p["in_off"] for p in table.paths if p["l3"] in used} == set(table.layout_in.offsets)
@@ -682,30 +706,32 @@ class SfcSpec:
 
 def _ptr_array(pairs):
     arr = (ctypes.c_void_p * 8)()
-    for l3, t in pairs:
-        arr[l3] = t.data_ptr()
+    for l3, addr in pairs:
+        arr[l3] = addr
     return arr
 
 
 class _SepFctp(Function):
+    """weight: flat [sum_l K(l) N1(l)] (e3nn LinearRS layout: one [K(l), N1(l)] block per degree, ascending);
+    weight2: flat [K(0) n2] or None.  The kernels read the blocks in place (no slicing / concatenation on the host)."""
+
     @staticmethod
-    def forward(ctx, x, coupling, w, bias, spec, *Ws):
-        x, coupling = _c(x), _c(coupling)
+    def forward(ctx, x, coupling, w, weight, bias, weight2, bias2, spec):
+        x, coupling, weight = _c(x), _c(coupling), _c(weight)
         w = _c(w) if w is not None else None
-        Ws = tuple(_c(W) for W in Ws)
-        _chk(x, coupling, w, bias, *Ws)
+        weight2 = _c(weight2) if weight2 is not None else None
+        _chk(x, coupling, w, weight, bias, weight2, bias2)
         E = x.shape[0]
-        assert len(Ws) == len(spec.degs)
-        for (l3, K, N1, ncat), W in zip(spec.degs, Ws):
-            assert tuple(W.shape) == (K, ncat), (tuple(W.shape), K, ncat)
+        assert weight.numel() == spec.weight_numel and (weight2 is None) == (spec.n2 == 0)
+        assert weight2 is None or weight2.numel() == spec.weight2_numel
         out1 = torch.empty((E, spec.out_layout.dim), device=x.device, dtype=torch.float32)
         out2 = torch.empty((E, spec.n2), device=x.device, dtype=torch.float32) if spec.n2 else None
-        Wl = _ptr_array((d[0], W) for d, W in zip(spec.degs, Ws))
-        call("eqf_sfc_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(bias), _p(out1),
+        Wl = _ptr_array((l3, weight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
+        call("eqf_sfc_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(bias), _p(weight2), _p(bias2), _p(out1),
              spec.out_layout.c_ref, _p(out2), spec.n2, E, _stream())
-        ctx.save_for_backward(x, coupling, w, *Ws)
+        ctx.save_for_backward(x, coupling, w, weight, weight2)
         ctx.spec = spec
-        ctx.has_bias = bias is not None
+        ctx.has_bias = (bias is not None, bias2 is not None)
         if out2 is None:
             return out1
         return out1, out2
@@ -713,7 +739,7 @@ class _SepFctp(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, d1, d2=None):
-        x, coupling, w, *Ws = ctx.saved_tensors
+        x, coupling, w, weight, weight2 = ctx.saved_tensors
         spec = ctx.spec
         E = x.shape[0]
         st = _stream()
@@ -725,45 +751,43 @@ class _SepFctp(Function):
         d1 = _c(d1)
         d2 = _c(d2) if spec.n2 else None
         _chk(d1, d2)
-        nW = len(Ws)
         need = ctx.needs_input_grad
-        dx = dM = dw = dbias = None
+        dx = dM = dw = dweight = dbias = dweight2 = dbias2 = None
         if need[0] or need[1] or (w is not None and need[2]):
             dx = (torch.empty_like if spec.in_covered else torch.zeros_like)(x)
             dw = torch.empty_like(w) if w is not None else None
             dM = torch.zeros_like(coupling) if need[1] else None
-            Wl = _ptr_array((d[0], W) for d, W in zip(spec.degs, Ws))
-            call("eqf_sfc_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(d1), spec.out_layout.c_ref,
-                 _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, st)
-        dWs = [None] * nW
-        want_b = ctx.has_bias and need[3]
-        if any(need[5:5 + nW]) or want_b:
-            sizes = [W.numel() for W in Ws]
-            flat = torch.zeros(sum(sizes) + (spec.bias_dim if want_b else 0), device=dev, dtype=torch.float32)
-            off = 0
-            for i, (W, n) in enumerate(zip(Ws, sizes)):
-                dWs[i] = flat[off:off + n].view_as(W)
-                off += n
-            if any(need[5:5 + nW]):
-                dWl = _ptr_array((d[0], g) for d, g in zip(spec.degs, dWs))
+            Wl = _ptr_array((l3, weight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
+            call("eqf_sfc_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(weight2), _p(d1),
+                 spec.out_layout.c_ref, _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, st)
+        want_b = ctx.has_bias[0] and need[4]
+        want_b2 = ctx.has_bias[1] and need[6]
+        if need[3] or need[5] or want_b or want_b2:
+            n1_0 = spec.out_layout.mul_of(0)
+            sizes = [spec.weight_numel, spec.weight2_numel, n1_0 if want_b else 0, spec.n2 if want_b2 else 0]
+            flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)  # ONE fill for every accumulated gradient
+            o1, o2, o3 = sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]
+            dweight = flat[:o1]
+            dweight2 = flat[o1:o2] if spec.n2 else None
+            if need[3] or need[5]:
+                dWl = _ptr_array((l3, flat.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
                 call("eqf_sfc_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref,
-                     _p(d2), spec.n2, dWl, E, st)
+                     _p(d2), spec.n2, dWl, _p(dweight2), E, st)
             if want_b:
-                dbias = flat[off:off + spec.bias_dim]
+                dbias = flat[o2:o3]
                 j = spec.out_layout.seg_index(0)
-                n1 = spec.out_layout.segs[j][0] if j is not None else 0
-                if n1:
-                    call("eqf_colsum", _p(d1, spec.out_layout.offsets[j]), rows(1, spec.out_layout.dim, 0), E, n1,
-                         _p(dbias), st)
-                if spec.n2:
-                    call("eqf_colsum", _p(d2), rows(1, spec.n2, 0), E, spec.n2, _p(dbias, n1), st)
-        return (dx, dM, dw, dbias, None) + tuple(dWs)
+                call("eqf_colsum", _p(d1, spec.out_layout.offsets[j]), rows(1, spec.out_layout.dim, 0), E, n1_0,
+                     _p(dbias), st)
+            if want_b2:
+                dbias2 = flat[o3:]
+                call("eqf_colsum", _p(d2), rows(1, spec.n2, 0), E, spec.n2, _p(dbias2), st)
+        return dx, dM, dw, dweight, dbias, dweight2, dbias2, None
 
 
-def sep_fctp(x, coupling, w, bias, spec, Ws):
-    """Fused DTP -> linear(s).  Ws: one [K(l3), N1(l3) (+ n2 for l3 == 0)] tensor per degree of spec.out_layout.
-    Returns out1 (and out2 when spec.n2 > 0)."""
-    return _SepFctp.apply(x, coupling, w, bias, spec, *Ws)
+def sep_fctp(x, coupling, w, weight, bias, spec, weight2=None, bias2=None):
+    """Fused DTP -> linear(s).  weight: flat LinearRS weight of the main consumer; weight2 / bias2: the second scalar
+    consumer (spec.n2 > 0).  Returns out1 (and out2 when spec.n2 > 0)."""
+    return _SepFctp.apply(x, coupling, w, weight, bias, weight2, bias2, spec)
 
 
 # ------------------------------------------------------------------------------------------------- attention

@@ -134,6 +134,23 @@ int eqf_gemm_nt(const float* A, eqf_rows ra, const float* B, int ldb, float* C, 
 int eqf_gemm_tn(const float* A, eqf_rows ra, const float* B, eqf_rows rb, float* C, int ldc, int M,
                 int N, int R, void* stream);
 
+/* Several independent GEMMs in ONE launch per kind (the per-degree GEMMs of one irreps linear; the node-level linears
+ * have only N ~ 2 k rows and are launch / latency bound).  n <= 4 problems.
+ *   kind 0:  C[i,n] (=|+=) sum_k A[i,k] B[k,n] (+ bias)     A: M two-level rows (ra) x K, B plain [K,N] (ldb), C rows (rc)
+ *   kind 1:  C[i,n] (=|+=) sum_k A[i,k] B[n,k] (+ bias)     B plain [N,K] (ldb)
+ *   kind 2:  C[m,n] += sum_{i<K} A[i,m] B[i,n]              A: K two-level rows (ra) x M, B: K two-level rows (rc) x N,
+ *                                                            C plain [M,N] with leading dimension ldb (atomics)
+ * [ref: LinearRS / FullyConnectedTensorProductRescale, nets/tensor_product_rescale.py:125-136,171-174] */
+typedef struct eqf_gemm_desc {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  eqf_rows ra, rc;
+  int ldb, M, N, K, accumulate, kind;
+} eqf_gemm_desc;
+int eqf_gemm_group(const eqf_gemm_desc* d, int n, void* stream);
+
 /* out[n] += sum_rows x[row, n]  over a two-level-row matrix (bias gradients). */
 int eqf_colsum(const float* X, eqf_rows rx, int R, int N, float* out, void* stream);
 
@@ -166,26 +183,27 @@ int eqf_dtp_linear_wgrad(const float* x, const float* coupling, const float* w,
 
 /* Fused SeparableFCTP (the edge hot loop): depth-wise tensor product -> per-degree linear for ALL output degrees and
  * ALL consumers of the DTP output in one launch; the DTP result is never written to memory in either direction.
- *   out1[e, seg(l3)]  = DTP(x, sh, w)[e, seg(l3)] . Wl[l3][:, 0:N1(l3)]                 for every degree of out1_irreps
- *   out2[e, 0:n2]     = DTP(x, sh, w)[e, seg(0)]  . Wl[0][:, N1(0):N1(0)+n2]            (optional second scalar consumer)
- * Wl[l3]: device pointers (HOST array indexed by l3) to row-major [K(l3), N1(l3) + (l3 == 0 ? n2 : 0)] matrices, K(l3) =
- * channels of the DTP output of degree l3; bias0 (may be NULL) has N1(0)+n2 entries and is added to the degree-0
- * columns.  out2 == NULL <=> n2 == 0.  w may be NULL (unit path weights).  Requires every path multiplicity and every
- * N1(l3)+n2 to be a multiple of 32.
+ *   out1[e, seg(l3)]  = DTP(x, sh, w)[e, seg(l3)] . Wl[l3]          (+ bias0 on degree 0)  for every degree of out1_irreps
+ *   out2[e, 0:n2]     = DTP(x, sh, w)[e, seg(0)]  . W2  (+ bias2)    optional second scalar consumer (attention logits)
+ * Wl[l3]: device pointers (HOST array indexed by l3) to row-major [K(l3), N1(l3)] matrices, K(l3) = channels of the DTP
+ * output of degree l3 -- e3nn's flat `tp.weight` of the LinearRS holds exactly these blocks in ascending degree, so
+ * the pointers go straight into the parameter; W2 is [K(0), n2].  out2 == NULL <=> n2 == 0 <=> W2 == NULL.  w may be
+ * NULL (unit path weights); bias0 [N1(0)] / bias2 [n2] may be NULL.  Requires every path multiplicity, every N1(l3) and
+ * n2 to be multiples of 32.
  * [ref: SeparableFCTP.forward nets/graph_attention_transformer.py:234-248 (dtp + lin) together with sep_alpha :492;
  *       EdgeDegreeEmbeddingNetwork.forward :725-733 (dw + proj)] */
 int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
-                const float* const* Wl, const float* bias0, float* out1, const eqf_irreps* out1_irreps, float* out2,
-                int n2, int E, void* stream);
+                const float* const* Wl, const float* bias0, const float* W2, const float* bias2, float* out1,
+                const eqf_irreps* out1_irreps, float* out2, int n2, int E, void* stream);
 /* Data gradient of eqf_sfc_fwd: dx[E,in_dim] written; dw[E,w_numel] written if non-NULL (ignored when w == NULL);
  * d_coupling[E,m_numel] (may be NULL; needed only when forces are differentiated) is ACCUMULATED with atomics. */
 int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
-                     const float* const* Wl, const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2,
-                     int n2, float* dx, float* dw, float* d_coupling, int E, void* stream);
-/* Weight gradient of eqf_sfc_fwd: dWl[l3] (same shapes as Wl[l3]) ACCUMULATED (fp32 atomics). */
+                     const float* const* Wl, const float* W2, const float* d_out1, const eqf_irreps* out1_irreps,
+                     const float* d_out2, int n2, float* dx, float* dw, float* d_coupling, int E, void* stream);
+/* Weight gradient of eqf_sfc_fwd: dWl[l3] / dW2 (same shapes as Wl[l3] / W2) ACCUMULATED (fp32 atomics). */
 int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
                        const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2, int n2,
-                       float* const* dWl, int E, void* stream);
+                       float* const* dWl, float* dW2, int E, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row-local feature ops (nodes or edges)

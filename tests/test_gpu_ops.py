@@ -397,22 +397,23 @@ def test_sfc_two_consumers_matches_unfused(irr, sh_irr, n2, E):
     w = torch.randn(E, table.weight_numel, generator=g).to(dev).requires_grad_(True)
     spec = ops.SfcSpec(table, lay_out, n2=n2)
     assert spec.supported
-    Ws = [(torch.randn(K, ncat, generator=g) / K ** 0.5).to(dev).requires_grad_(True) for (_, K, _, ncat) in spec.degs]
-    bias = torch.randn(spec.bias_dim, generator=g).to(dev).requires_grad_(True)
+    weight = (torch.randn(spec.weight_numel, generator=g) / 16).to(dev).requires_grad_(True)
+    weight2 = (torch.randn(spec.weight2_numel, generator=g) / 16).to(dev).requires_grad_(True)
+    n1_0 = lay_out.mul_of(0)
+    bias = torch.randn(n1_0, generator=g).to(dev).requires_grad_(True)
+    bias2 = torch.randn(n2, generator=g).to(dev).requires_grad_(True)
     M = ops.dtp_coupling(sh, table)
-    o1, o2 = ops.sep_fctp(x, M, w, bias, spec, Ws)
+    o1, o2 = ops.sep_fctp(x, M, w, weight, bias, spec, weight2=weight2, bias2=bias2)
     # reference composition on the GPU from the un-fused primitives
     mid = ops.dtp(x, ops.dtp_coupling(sh, table), w, table)
     lin_spec = ops.LinearSpec(lay_mid, lay_out)
-    n1_0 = lay_out.mul_of(0)
-    flat = torch.cat([W[:, :N1].reshape(-1) for (_, _, N1, _), W in zip(spec.degs, Ws)])
-    r1 = ops.irreps_linear(mid, flat, bias[:n1_0], lin_spec)
+    r1 = ops.irreps_linear(mid, weight, bias, lin_spec)
     K0 = spec.degs[0][1]
-    r2 = mid[:, :K0] @ Ws[0][:, n1_0:] + bias[n1_0:]
+    r2 = mid[:, :K0] @ weight2.view(K0, n2) + bias2
     assert _rel(o1, r1) < 1e-5 and _rel(o2, r2) < 1e-5
     g1 = torch.randn(o1.shape, generator=g).to(dev)
     g2 = torch.randn(o2.shape, generator=g).to(dev)
-    ins = [x, sh, w, bias] + Ws
+    ins = [x, sh, w, bias, bias2, weight, weight2]
     ga = torch.autograd.grad([o1, o2], ins, [g1, g2])
     gb = torch.autograd.grad([r1, r2], ins, [g1, g2])
     for i, (a, b) in enumerate(zip(ga, gb)):

@@ -41,21 +41,25 @@ def run(name, irr, sh_irr, out_irr, n2, use_w):
     x = torch.randn(E, table.layout_in.dim, generator=g).to(dev)
     M = torch.randn(E, table.m_numel, generator=g).to(dev)
     w = torch.randn(E, table.weight_numel, generator=g).to(dev) if use_w else None
-    Ws = [torch.randn(K, ncat, generator=g).to(dev) for (_, K, _, ncat) in spec.degs]
-    dWs = [torch.zeros_like(W) for W in Ws]
+    weight = torch.randn(spec.weight_numel, generator=g).to(dev)
+    weight2 = torch.randn(spec.weight2_numel, generator=g).to(dev) if n2 else None
+    dweight = torch.zeros_like(weight)
+    dweight2 = torch.zeros_like(weight2) if n2 else None
     o1 = torch.empty(E, lay.dim, device=dev)
     o2 = torch.empty(E, n2, device=dev) if n2 else None
     d1 = torch.randn(E, lay.dim, generator=g).to(dev)
     d2 = torch.randn(E, n2, generator=g).to(dev) if n2 else None
     dx = torch.empty_like(x)
     dw = torch.empty_like(w) if use_w else None
-    Wl = ops._ptr_array((d[0], W) for d, W in zip(spec.degs, Ws))
-    dWl = ops._ptr_array((d[0], W) for d, W in zip(spec.degs, dWs))
+    Wl = ops._ptr_array((d[0], weight.data_ptr() + 4 * o) for d, o in zip(spec.degs, spec.w_offs))
+    dWl = ops._ptr_array((d[0], dweight.data_ptr() + 4 * o) for d, o in zip(spec.degs, spec.w_offs))
     flops = sum(2.0 * E * (2 * l3 + 1) * K * ncat for (l3, K, _, ncat) in spec.degs)
-    f = lambda: call("eqf_sfc_fwd", P(x), P(M), P(w), table.c_ref, Wl, None, P(o1), lay.c_ref, P(o2), n2, E, st())
-    b = lambda: call("eqf_sfc_bwd_data", P(x), P(M), P(w), table.c_ref, Wl, P(d1), lay.c_ref, P(d2), n2, P(dx), P(dw),
-                     None, E, st())
-    wg = lambda: call("eqf_sfc_bwd_weight", P(x), P(M), P(w), table.c_ref, P(d1), lay.c_ref, P(d2), n2, dWl, E, st())
+    f = lambda: call("eqf_sfc_fwd", P(x), P(M), P(w), table.c_ref, Wl, None, P(weight2), None, P(o1), lay.c_ref, P(o2),
+                     n2, E, st())
+    b = lambda: call("eqf_sfc_bwd_data", P(x), P(M), P(w), table.c_ref, Wl, P(weight2), P(d1), lay.c_ref, P(d2), n2,
+                     P(dx), P(dw), None, E, st())
+    wg = lambda: call("eqf_sfc_bwd_weight", P(x), P(M), P(w), table.c_ref, P(d1), lay.c_ref, P(d2), n2, dWl, P(dweight2),
+                      E, st())
     from equiformer_amd import lib as _lib
     dbg = torch.zeros(8, dtype=torch.int64, device=dev)
     _lib.load().eqf_sfc_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
