@@ -322,7 +322,9 @@ struct SfcWgArgs {
   SfcCommon c;
   int nitem;
   int echunk;  // edges per workgroup (multiple of 8)
-  short item_slab[2 * SFC_MAX_SLABS];  // global slab index
+  short item_slab[2 * SFC_MAX_SLABS];  // global index of the group's first slab
+  short item_ns[2 * SFC_MAX_SLABS];    // slabs in the group (1..4)
+  short item_cls[2 * SFC_MAX_SLABS];   // compile-time tile count of the item's body: 1, 2, 4 or 8
   short item_col0[2 * SFC_MAX_SLABS];  // first column (multiple of 32) of the item's column range
   short item_ct[2 * SFC_MAX_SLABS];    // number of 32-column tiles
 };
@@ -423,20 +425,21 @@ __device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, co
   }
 }
 
+// Workgroup = (group of up to 4 slabs of one degree sharing a column range, chunk of edges): wave w owns slab w of the
+// group over the WHOLE chunk, so the four waves stream the same d_out rows at the same time (one HBM fetch, three L1 /
+// L2 hits) and every wave finishes with its own [32 x CTT*32] block of the weight gradient -- no cross-wave reduction.
 template <int CTT, int MAXD>
-__global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
-  __shared__ float Msh[4][W_SUB * MAXD * MAXD];  // per wave: [edge][i*d3 + m3] of the slab's path
-  __shared__ float Red[2][32 * CTT * 32];          // cross-wave reduction slots
-  const int item = blockIdx.y;
-  const SfcSlab S = g.c.slab[g.item_slab[item]];
+__device__ __forceinline__ void wg_item(const SfcWgArgs& g, const int item, float (&Msh)[4][W_SUB * MAXD * MAXD]) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= g.item_ns[item]) return;  // a group of fewer than 4 slabs
+  const int slab = g.item_slab[item] + wave;
+  const SfcSlab S = g.c.slab[slab];
   const SfcDeg& D = g.c.deg[S.deg];
   const int col0 = g.item_col0[item], CT = g.item_ct[item];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
-  // edge range of this wave (even start)
-  const int per = g.echunk >> 2;
-  const int ebeg = blockIdx.x * g.echunk + wave * per;
-  const int eend = min(g.c.E, ebeg + per);
+  const int ebeg = blockIdx.x * g.echunk;
+  const int eend = min(g.c.E, ebeg + g.echunk);
+  if (ebeg >= eend) return;
 
   f32x16 acc[CTT];
 #pragma unroll
@@ -467,30 +470,8 @@ __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
 #undef WG_D3
 #undef WG_CASE
 
-  // sum the four waves' accumulators through LDS (tree: 2,3 -> 0,1 ; 1 -> 0), then ONE set of atomics per workgroup
-  constexpr int RW = CTT * 32;  // row length of a [32 channels][RW] slot
-  auto put = [&](float* slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ct = 0; ct < CTT; ++ct)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) slot[((q & 3) + 8 * (q >> 2) + 4 * hi) * RW + ct * 32 + r] = acc[ct][q];
-  };
-  auto take = [&](const float* slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ct = 0; ct < CTT; ++ct)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[ct][q] += slot[((q & 3) + 8 * (q >> 2) + 4 * hi) * RW + ct * 32 + r];
-  };
-  if (wave >= 2) put(Red[wave - 2]);
-  __syncthreads();
-  if (wave < 2) take(Red[wave]);
-  __syncthreads();
-  if (wave == 1) put(Red[0]);
-  __syncthreads();
-  if (wave != 0) return;
-  take(Red[0]);
   // C[i = channel of the slab][j = column]
-  const int slab_in_deg = g.item_slab[item] - D.slab0;
+  const int slab_in_deg = slab - D.slab0;
 #pragma unroll
   for (int ct = 0; ct < CTT; ++ct)
     if (ct < CT) {
@@ -503,6 +484,28 @@ __global__ __launch_bounds__(256) void sfc_wgrad_kernel(const SfcWgArgs g) {
         atomicAdd(base + ch * ldw + r, acc[ct][q]);
       }
     }
+}
+
+// ONE launch for all items: grid.y enumerates the items of every column-tile class (1, 2, 4, 8 tiles), sorted wide
+// first; a single large grid packs the CUs better than one launch per class.
+template <int MAXD>
+__global__ __launch_bounds__(256, 2) void sfc_wgrad_kernel(const SfcWgArgs g_byval) {
+  // read the argument block in place (kernarg segment): with four instantiated bodies hipcc otherwise copies the
+  // by-value struct to scratch and serves every table lookup from there
+#if defined(__HIP_DEVICE_COMPILE__)
+  const SfcWgArgs& g = *(const SfcWgArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)g_byval;
+#else
+  const SfcWgArgs& g = g_byval;
+#endif
+  __shared__ float Msh[4][W_SUB * MAXD * MAXD];  // per wave: [edge][i*d3 + m3] of the slab's path
+  const int item = blockIdx.y;
+  switch (g.item_cls[item]) {
+    case 8: wg_item<8, MAXD>(g, item, Msh); break;
+    case 4: wg_item<4, MAXD>(g, item, Msh); break;
+    case 2: wg_item<2, MAXD>(g, item, Msh); break;
+    default: wg_item<1, MAXD>(g, item, Msh); break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ data gradient
@@ -974,9 +977,9 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
     if (!A.c.deg[d].dW) return EQF_E_BADARG;
   const int pid = eqf_prof_begin("sfc_wgrad", st, sfc_flops(A.c), sfc_bytes(A.c));
   const int classes[4] = {8, 4, 2, 1};
+  A.nitem = 0;
   for (int ci = 0; ci < 4; ++ci) {
     const int cls = classes[ci];
-    A.nitem = 0;
     for (int d = 0; d < A.c.ndeg; ++d) {
       const SfcDeg& D = A.c.deg[d];
       int ct0 = 0, rem = D.Ncat / 32;
@@ -987,43 +990,32 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
         else take = rem;  // 1 or 2
         used = rem < take ? rem : take;
         if (take == cls)
-          for (int q = 0; q < D.nslab; ++q) {
+          for (int q = 0; q < D.nslab; q += 4) {
             if (A.nitem >= 2 * SFC_MAX_SLABS) return EQF_E_UNSUPPORTED;
             A.item_slab[A.nitem] = (short)(D.slab0 + q);
+            A.item_ns[A.nitem] = (short)(D.nslab - q < 4 ? D.nslab - q : 4);
             A.item_col0[A.nitem] = (short)(ct0 * 32);
             A.item_ct[A.nitem] = (short)used;
+            A.item_cls[A.nitem] = (short)cls;
             A.nitem++;
           }
         ct0 += used, rem -= used;
       }
     }
-    if (A.nitem == 0) continue;
-    // few, long-running workgroups: every workgroup ends with 32 x 32 x CTT atomics, and the wide kernels run at one
-    // workgroup per CU
-    const int target = cls >= 8 ? 512 : (cls == 4 ? 768 : 1024);
-    int z = eqf_cdiv(target, A.nitem);
+  }
+  if (A.nitem > 0) {
+    // few, long-running workgroups: every wave ends with 32 x 32 x CTT atomics
+    int z = eqf_cdiv(1536, A.nitem);
     int echunk = eqf_cdiv(E, z);
     echunk = ((echunk + 7) / 8) * 8;
-    if (echunk < 256) echunk = 256;
+    if (echunk < 128) echunk = 128;
     A.echunk = echunk;
     z = eqf_cdiv(E, echunk);
     dim3 grid(z, A.nitem);
-#define LAUNCH_WG(CTT)                                                                                     \
-  do {                                                                                                     \
-    if (md <= 5)                                                                                           \
-      hipLaunchKernelGGL((sfc_wgrad_kernel<CTT, 5>), grid, dim3(256), 0, st, A);                           \
-    else                                                                                                   \
-      hipLaunchKernelGGL((sfc_wgrad_kernel<CTT, 7>), grid, dim3(256), 0, st, A);                           \
-  } while (0)
-    if (cls == 8)
-      LAUNCH_WG(8);
-    else if (cls == 4)
-      LAUNCH_WG(4);
-    else if (cls == 2)
-      LAUNCH_WG(2);
+    if (md <= 5)
+      hipLaunchKernelGGL((sfc_wgrad_kernel<5>), grid, dim3(256), 0, st, A);
     else
-      LAUNCH_WG(1);
-#undef LAUNCH_WG
+      hipLaunchKernelGGL((sfc_wgrad_kernel<7>), grid, dim3(256), 0, st, A);
     EQF_CHECK_LAUNCH();
   }
   eqf_prof_end(pid, st);

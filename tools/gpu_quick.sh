@@ -1,3 +1,3 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1r; export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1v; export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "sfc or separable" 2>&1 | tail -5
-timeout 200 python tools/bench_sfc.py 2>&1 | tee gpurun_out/r1r/bench_sfc.txt
+timeout 200 python tools/bench_sfc.py 2>&1 | tee gpurun_out/r1v/bench_sfc.txt
