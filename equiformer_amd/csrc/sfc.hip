@@ -98,6 +98,7 @@ struct SfcFwdArgs {
   SfcCommon c;
   const float* bias;   // [N1 of degree 0] or null
   const float* bias2;  // [N2] or null
+  unsigned long long* dbg;  // optional phase timers (development aid), may be null
   int nsplit[SFC_MAX_DEG], cps[SFC_MAX_DEG], blk0[SFC_MAX_DEG + 1];
 };
 
@@ -152,7 +153,6 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
   const int m_len = D.m_len;
 
   const int t = threadIdx.x;
-  const int u = t & 31, grp = t >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = t & 63, r = lane & 31, hi = lane >> 5;
 
@@ -182,22 +182,31 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     sfc_lds[MT0 + i] = (el < ecnt) ? g.c.coupling[(long)(e0 + el) * g.c.m_ld + D.m_base + j] : 0.f;
   }
 
-  // per-thread edge offsets (clamped: out-of-range edges read a valid row and are masked by vmask)
-  // edge of slot p: e0 + min(grp + 8p, ecnt - 1)  (recomputed where needed instead of held in registers)
-  const int elast = ecnt - 1;
+  // Generation mapping: thread = (channel quad c4 = t & 7 -> channels 4 c4 .. 4 c4 + 3 of the slab, edges eg and eg + 32
+  // with eg = t >> 3).  x and w are fetched as 16-byte vectors (8 lanes x 16 B = one 128-byte channel run per edge):
+  // 4x fewer, 4x wider loads than a thread-per-channel mapping, and every coupling entry read from LDS feeds 4 FMAs.
+  const int c4 = t & 7, eg = t >> 3;
   const unsigned x_ld = g.c.x_ld, w_ld = g.c.w_ld;
+  unsigned erow[2];  // clamped global edge index (out-of-range edges read a valid row and are zeroed by the mask)
+  float emask[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int el = eg + 32 * q;
+    erow[q] = e0 + (el < ecnt ? el : 0);
+    emask[q] = (el < ecnt) ? 1.0f : 0.f;
+  }
 
-  float xv[F_NP][MAXD], wv[F_NP];
+  f32x4 xv[2][MAXD], wv[2];
   f32x4 bv[CTCAP];
   int s_d1 = 0, s_mo = 0;  // of the slab whose inputs are in xv / wv / bv
   auto load_x = [&](auto tag, const SfcSlab& S) __attribute__((always_inline)) {
     constexpr int D1 = decltype(tag)::value;
-    const float* xs = g.c.x + S.x_off;
+    const float* xs = g.c.x + S.x_off + 4 * c4;
 #pragma unroll
     for (int i = 0; i < D1; ++i) {
       const float* xi = xs + i * S.x_mul;
 #pragma unroll
-      for (int p = 0; p < F_NP; ++p) xv[p][i] = xi[(unsigned)(e0 + min(grp + 8 * p, elast)) * x_ld + u];
+      for (int q = 0; q < 2; ++q) xv[q][i] = *reinterpret_cast<const f32x4*>(xi + erow[q] * x_ld);
     }
   };
   auto issue = [&](int s) __attribute__((always_inline)) {
@@ -205,12 +214,12 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     s_d1 = S.d1;
     s_mo = S.m_off - D.m_base;
     if (g.c.w) {
-      const float* ws = g.c.w + S.w_off;
+      const float* ws = g.c.w + S.w_off + 4 * c4;
 #pragma unroll
-      for (int p = 0; p < F_NP; ++p) wv[p] = ws[(unsigned)(e0 + min(grp + 8 * p, elast)) * w_ld + u];
+      for (int q = 0; q < 2; ++q) wv[q] = *reinterpret_cast<const f32x4*>(ws + erow[q] * w_ld);
     } else {
 #pragma unroll
-      for (int p = 0; p < F_NP; ++p) wv[p] = 1.0f;
+      for (int q = 0; q < 2; ++q) wv[q] = f32x4{1.f, 1.f, 1.f, 1.f};
     }
     switch (S.d1) {
       case 1: load_x(IC<1>(), S); break;
@@ -228,20 +237,22 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
       bv[j] = *reinterpret_cast<const f32x4*>(wp + 4 * (t & 7));
     }
   };
-  const int awb = AS0 + u * SA + grp;
-  const int mrow = MT0 + grp * m_len;
+  const int awb = AS0 + (4 * c4) * SA + eg;
+  const int mrow = MT0 + eg * m_len;
   auto gen = [&](auto tag) __attribute__((always_inline)) {
     constexpr int D1 = decltype(tag)::value;
 #pragma unroll
-    for (int p = 0; p < F_NP; ++p) {
-      const int mp = mrow + (8 * p) * m_len + s_mo;
-      const float wm = (grp + 8 * p < ecnt) ? wv[p] : 0.f;
+    for (int q = 0; q < 2; ++q) {
+      const int mp = mrow + (32 * q) * m_len + s_mo;
+      const f32x4 wm = wv[q] * emask[q];
 #pragma unroll
       for (int m3 = 0; m3 < D3; ++m3) {
-        float a = 0.f;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < D1; ++i) a = fmaf(sfc_lds[mp + i * D3 + m3], xv[p][i], a);
-        sfc_lds[awb + 8 * p + m3 * F_TE] = a * wm;
+        for (int i = 0; i < D1; ++i) a += xv[q][i] * sfc_lds[mp + i * D3 + m3];
+        a *= wm;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sfc_lds[awb + c * SA + 32 * q + m3 * F_TE] = a[c];
       }
     }
   };
@@ -257,13 +268,25 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     for (int j = 0; j < CTCAP; ++j) *reinterpret_cast<f32x4*>(&sfc_lds[bwp + 32 * j]) = bv[j];
   };
 
+  unsigned long long t_mark = g.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  auto tick = [&](int slot) __attribute__((always_inline)) {
+    if (g.dbg) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (t == 0) atomicAdd(g.dbg + slot, now - t_mark);
+      t_mark = now;
+    }
+  };
   issue(0);
   __syncthreads();
+  tick(0);  // prologue
   const int nslab = D.nslab;
   for (int s = 0; s < nslab; ++s) {
     commit();
+    tick(1);  // wait for the prefetched inputs + generation + LDS writes
     __syncthreads();
+    tick(2);  // barrier
     if (s + 1 < nslab) issue(s + 1);
+    tick(3);  // issue of the next slab's loads
     switch (NT) {
       case 1: f_mma<D3, 1, FT>(aidx, bidx, acc); break;
       case 2: f_mma<D3, 2, FT>(aidx, bidx, acc); break;
@@ -272,7 +295,9 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
         if constexpr (FT >= 4) f_mma<D3, 4, FT>(aidx, bidx, acc);
         break;
     }
+    tick(4);  // MFMA loop
     __syncthreads();
+    tick(5);  // barrier
   }
 
   // epilogue: row = m3 * 64 + el ; column c of the concatenated output
@@ -911,6 +936,7 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
   if (E <= 0) return 0;
   A.bias = bias0;
   A.bias2 = bias2;
+  A.dbg = g_sfc_dbg;
   int md = max_d1(A.c);
   for (int d = 0; d < A.c.ndeg; ++d) md = A.c.deg[d].d3 > md ? A.c.deg[d].d3 : md;
   const int ft = md <= 5 ? 3 : F_MAXT;

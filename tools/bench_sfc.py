@@ -63,6 +63,13 @@ def run(name, irr, sh_irr, out_irr, n2, use_w):
     from equiformer_amd import lib as _lib
     dbg = torch.zeros(8, dtype=torch.int64, device=dev)
     _lib.load().eqf_sfc_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
+    f()
+    torch.cuda.synchronize()
+    d = dbg.cpu().tolist()
+    tot = sum(d[:7]) or 1
+    print("%-10s fwd phase share (wave 0): prologue %.2f commit %.2f barrier %.2f issue(B) %.2f mfma %.2f barrier %.2f issue(x,w) %.2f"
+          % ((name,) + tuple(v / tot for v in d[:7])), flush=True)
+    dbg.zero_()
     b()
     torch.cuda.synchronize()
     _lib.load().eqf_sfc_debug_buffer(None)

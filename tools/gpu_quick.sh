@@ -1,3 +1,3 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1w; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/r1w/pmc1 -o p1 -- python tools/bench_sfc.py > gpurun_out/r1w/pmc1.log 2>&1
-tail -2 gpurun_out/r1w/pmc1.log
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1y; export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "sfc or separable" 2>&1 | tail -5
+timeout 200 python tools/bench_sfc.py 2>&1 | tee gpurun_out/r1y/bench_sfc.txt
