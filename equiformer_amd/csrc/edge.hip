@@ -484,7 +484,7 @@ int eqf_alpha_bwd(const float* a, const float* alpha_dot, const float* d_logit, 
                   int H, int Kh, float c, void* stream) {
   if (!a || !alpha_dot || !d_logit || !da || !d_alpha_dot) return EQF_E_BADARG;
   if (E <= 0) return 0;
-  const int CH = 128;
+  const int CH = 16;  // few edges per thread (serial loop), one atomic per column and workgroup
   hipLaunchKernelGGL(alpha_bwd_kernel, dim3(eqf_cdiv(H * Kh, 128), eqf_cdiv(E, CH)), dim3(128), 0, (hipStream_t)stream,
                      a, alpha_dot, d_logit, da, d_alpha_dot, E, H * Kh, Kh, c, CH);
   EQF_CHECK_LAUNCH();

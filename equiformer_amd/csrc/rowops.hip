@@ -382,7 +382,7 @@ int eqf_layernorm_bwd(const float* x, const float* weight, const float* dy, cons
                      weight, dy, rstd, dx, rows, T);
   EQF_CHECK_LAUNCH();
   if (d_weight && d_bias) {
-    const int CH = 64;
+    const int CH = 16;  // few rows per thread: the row loop is a chain of dependent loads
     hipLaunchKernelGGL(layernorm_wgrad_kernel, dim3(eqf_cdiv(T.D, 256), eqf_cdiv(rows, CH)), dim3(256), 0,
                        (hipStream_t)stream, x, dy, rstd, mean0, d_weight, d_bias, rows, T, CH);
     EQF_CHECK_LAUNCH();
@@ -450,8 +450,8 @@ int eqf_lnsilu_bwd(const float* x, const float* gamma, const float* beta, const 
   if (!x || !gamma || !beta || !dy || !dx || !d_gamma || !d_beta || C < 1) return EQF_E_BADARG;
   if (C > 64) return EQF_E_UNSUPPORTED;
   if (rows <= 0) return 0;
-  int blocks = eqf_cdiv(rows, WAVES_PER_BLOCK * 8);
-  if (blocks > 2048) blocks = 2048;
+  int blocks = eqf_cdiv(rows, WAVES_PER_BLOCK * 2);  // two rows per wave: the loop is a chain of dependent reductions
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(lnsilu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy, dx,
                      d_gamma, d_beta, rows, C, eps);
   EQF_CHECK_LAUNCH();

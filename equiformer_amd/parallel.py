@@ -37,21 +37,25 @@ class FlatGradAllReduce:
             dist.broadcast(p.data, src=src, group=self.group)
 
     def reduce(self):
-        """Gather .grad into the flat buffer, all-reduce(mean), scatter back.  Call after backward()."""
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
+        """Pack every .grad into the flat buffer (multi-tensor copy: a handful of launches, not one per parameter),
+        all-reduce(mean) it in ONE collective, and re-point each .grad at its slice of the buffer (no copy back).
+        Call after backward()."""
+        have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
+        missing = [v for p, v in zip(self.params, self.views) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
         ws = self.world_size()
         if ws > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(ws)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
+            backend = dist.get_backend(self.group)
+            if backend == "nccl":  # RCCL averages in the collective itself
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
             else:
-                p.grad.copy_(v)
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.div_(ws)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
         return self.flat
 
 
