@@ -381,9 +381,11 @@ __device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, co
   const float* ws = g.c.w ? g.c.w + S.w_off : nullptr;
   const unsigned x_ld = g.c.x_ld, w_ld = g.c.w_ld, x_mul = S.x_mul;
 
-  // raw inputs (x, w, d_out values) of the next PF edge pairs, rotated through registers: wide items run at one wave per
-  // SIMD, where only the wave's own look-ahead hides the memory latency behind its MFMAs
-  constexpr int PF = (CTT >= 4) ? 2 : 1;
+  // Raw inputs (x, w, d_out values) of the next PF edge pairs live in a ring of PF statically named register slots
+  // (the step loop is unrolled by PF, so there is no register rotation): a step's MFMAs are only D3 * CTT * 64 cycles
+  // -- 320 for the degree-2 items -- against ~2 us of memory latency, so narrow items need a deep look-ahead.
+  constexpr int PF = 4;
+  static_assert(W_SUB % (2 * PF) == 0, "a group of PF steps must not straddle a coupling block");
   float xq[PF][D1], wq[PF], bq[PF][D3][CTT];
   auto fetch = [&](int e, int slot) __attribute__((always_inline)) {
     const int ee = e + hi;
@@ -413,40 +415,35 @@ __device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, co
   stage_m(sub0);
 #pragma unroll
   for (int u = 0; u < PF; ++u) fetch(ebeg + 2 * u, u);
-  for (int e = ebeg; e < eend; e += 2) {
-    if (e >= sub0 + W_SUB) {
-      sub0 = e;
+  for (int e0 = ebeg; e0 < eend; e0 += 2 * PF) {  // steps past eend (at most PF - 1) run with w = 0
+    if (e0 >= sub0 + W_SUB) {
+      sub0 = e0;
       stage_m(sub0);
     }
-    // form the A values of this pair from the prefetched x, w and the LDS-resident coupling matrices
-    const int ee = (e + hi < eend) ? e + hi : e;
-    const float* mp = Mw + (ee - sub0) * LEN;
-    float a[D3], bc[D3][CTT];
 #pragma unroll
-    for (int m3 = 0; m3 < D3; ++m3) {
-      float v = 0.f;
+    for (int u = 0; u < PF; ++u) {
+      const int e = e0 + 2 * u;
+      // form the A values of this pair from slot u and the LDS-resident coupling matrices (rows of edges past the
+      // range are clamped to the last valid edge: their w is 0, the coupling entry must merely be finite)
+      const int ee = (e + hi < eend) ? e + hi : eend - 1;
+      const float* mp = Mw + (ee - sub0) * LEN;
+      float a[D3], bc[D3][CTT];
 #pragma unroll
-      for (int i = 0; i < D1; ++i) v = fmaf(mp[i * D3 + m3], xq[0][i], v);
-      a[m3] = v * wq[0];
+      for (int m3 = 0; m3 < D3; ++m3) {
+        float v = 0.f;
 #pragma unroll
-      for (int ct = 0; ct < CTT; ++ct) bc[m3][ct] = bq[0][m3][ct];
-    }
+        for (int i = 0; i < D1; ++i) v = fmaf(mp[i * D3 + m3], xq[u][i], v);
+        a[m3] = v * wq[u];
 #pragma unroll
-    for (int u = 0; u + 1 < PF; ++u) {
-#pragma unroll
-      for (int i = 0; i < D1; ++i) xq[u][i] = xq[u + 1][i];
-      wq[u] = wq[u + 1];
+        for (int ct = 0; ct < CTT; ++ct) bc[m3][ct] = bq[u][m3][ct];
+      }
+      fetch(e + 2 * PF, u);  // consumed PF steps from now; out-of-range pairs re-read a valid row with w = 0
 #pragma unroll
       for (int m3 = 0; m3 < D3; ++m3)
 #pragma unroll
-        for (int ct = 0; ct < CTT; ++ct) bq[u][m3][ct] = bq[u + 1][m3][ct];
+        for (int ct = 0; ct < CTT; ++ct)  // no guards here: a conditional MFMA makes hipcc shuttle the accumulators
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m3], bc[m3][ct], acc[ct], 0, 0, 0);
     }
-    fetch(e + 2 * PF, PF - 1);  // in flight while the matrix pipe works; out-of-range pairs re-read a valid row, w = 0
-#pragma unroll
-    for (int m3 = 0; m3 < D3; ++m3)
-#pragma unroll
-      for (int ct = 0; ct < CTT; ++ct)  // no guards here: a conditional MFMA makes hipcc shuttle the accumulators
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m3], bc[m3][ct], acc[ct], 0, 0, 0);
   }
 }
 
