@@ -707,20 +707,24 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
         // LDS operands (aA / aB) and the weight fragments (bA / bB) of a block are requested one block / two blocks
         // before its MFMAs are issued.
         auto seg = [&](const int kb0, const int kb1, const float* rowp) __attribute__((always_inline)) {
+          // Weight fragments are requested FOUR k blocks (16 * D3 MFMAs) before their use: with one row tile (D3 == 1)
+          // two blocks are only 256 cycles, less than an L2 round trip.  (bA, bB) hold blocks kb, kb+16 on entry;
+          // (bC, bD) the following pair.  LDS operands (aA / aB) ping-pong one block ahead.
+          const float* wp = rowp + kc0;
+          f32x4 bC = *reinterpret_cast<const f32x4*>(wp + (kb0 + 32 < kb1 ? kb0 + 32 : kb0));
+          f32x4 bD = *reinterpret_cast<const f32x4*>(wp + (kb0 + 48 < kb1 ? kb0 + 48 : kb0));
           float aA[4][D3], aB[4][D3];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int rt = 0; rt < D3; ++rt) aA[jj][rt] = ap[jj * SD + rt * 32];
-          const float* wp = rowp + kc0;
-#pragma unroll 1
-          for (int kb = kb0; kb < kb1; kb += 32) {
+          auto pair = [&](f32x4& p0, f32x4& p1, const int kb) __attribute__((always_inline)) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
               for (int rt = 0; rt < D3; ++rt) aB[jj][rt] = ap[(16 + jj) * SD + rt * 32];
-            const f32x4 b0 = bA;
-            bA = *reinterpret_cast<const f32x4*>(wp + (kb + 32 < kb1 ? kb + 32 : kb0));
+            const f32x4 b0 = p0;
+            p0 = *reinterpret_cast<const f32x4*>(wp + (kb + 64 < kb1 ? kb + 64 : kb0));
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -732,14 +736,21 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
               for (int rt = 0; rt < D3; ++rt) aA[jj][rt] = ap[jj * SD + rt * 32];
-            const f32x4 b1 = bB;
-            bB = *reinterpret_cast<const f32x4*>(wp + (kb + 48 < kb1 ? kb + 48 : kb0));
+            const f32x4 b1 = p1;
+            p1 = *reinterpret_cast<const f32x4*>(wp + (kb + 80 < kb1 ? kb + 80 : kb0));
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
               for (int rt = 0; rt < D3; ++rt)
                 acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[jj][rt], b1[jj], acc[jj & 1][rt], 0, 0, 0);
+          };
+          int kb = kb0;
+#pragma unroll 1
+          for (; kb + 64 <= kb1; kb += 64) {
+            pair(bA, bB, kb);
+            pair(bC, bD, kb + 32);
           }
+          if (kb < kb1) pair(bA, bB, kb);  // segment lengths are multiples of 32: at most one pair is left
         };
         seg(0, endA, rowA);
         if (endA < kcn) {
