@@ -100,12 +100,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks (not used by the driver): EQF_BENCH_DEVICE pins every rank to one GPU and EQF_BENCH_BACKEND=gloo lets
+    # the N > 1 code path run on a single-GPU box
+    dev_index = int(os.environ.get("EQF_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+        dist.init_process_group(os.environ.get("EQF_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)  # RCCL / xGMI
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from equiformer_amd import lib, nets

@@ -1,3 +1,3 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2b; export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "sfc or separable" 2>&1 | tail -3
-timeout 200 python tools/bench_sfc.py 2>&1 | tee gpurun_out/r2b/bench_sfc.txt
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2d; export TMPDIR=/tmp
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+EQF_BENCH_DEVICE=0 EQF_BENCH_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline 2>&1 | tail -4 | cut -c1-400
