@@ -4,9 +4,10 @@ Drop-in for the reference's nets/graph_attention_transformer_md17.py (`GraphAtte
 `*_md17` factories :330-519): `forward(node_atom, pos, batch) -> (energy [B,1], forces [N,3])`, works under an outer
 `torch.no_grad()`, reads `task_mean/task_std`.
 
-Round-1 limitation: forces come from a first-order backward pass, so they carry no autograd graph
-(`create_graph=True` of the reference, nets/graph_attention_transformer_md17.py:318-325); training on the force loss
-needs the double-backward kernels that are scheduled next.
+In training mode the forces are produced with `create_graph=True` (reference: nets/graph_attention_transformer_md17.py:
+318-325), i.e. `loss.backward()` on a force loss is a second-order pass; see `equiformer_amd/second_order.py` for how
+the HIP operators support it.  In eval mode (force evaluation, main_md17.py:444-452) the forces come from the plain
+first-order HIP backward and carry no graph.
 """
 import torch
 
@@ -62,8 +63,10 @@ class GraphAttentionTransformerMD17(_Trunk):
         energy = self._trunk_forward(atom_embedding, pos, graph)
         if self.scale is not None:
             energy = self.scale * energy
-        keep = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        forces = -1 * torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), retain_graph=keep)[0]
+        trainable = any(p.requires_grad for p in self.parameters())
+        second_order = self.training and trainable
+        forces = -1 * torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), create_graph=second_order,
+                                          retain_graph=trainable)[0]
         return energy, forces
 
 

@@ -12,6 +12,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import lib
+from . import second_order as so
 from .lib import EqfGemmDesc, EqfRows, call
 
 
@@ -68,15 +69,18 @@ class _LayerNorm(Function):
         mean0 = torch.empty((n,), device=x.device, dtype=torch.float32)
         call("eqf_layernorm_fwd", _p(x), _p(weight), _p(bias), _p(y), _p(rstd), _p(mean0), n, layout.c_ref,
              float(eps), _stream())
-        ctx.save_for_backward(x, weight, rstd, mean0)
+        ctx.save_for_backward(x, weight, rstd, mean0, bias)
         ctx.layout = layout
         ctx.nb = bias.numel()
+        ctx.eps = eps
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
-        x, weight, rstd, mean0 = ctx.saved_tensors
+        x, weight, rstd, mean0, bias = ctx.saved_tensors
+        if torch.is_grad_enabled():  # create_graph: differentiable restatement (second_order.py)
+            gx, gw, gb = so.vjp(lambda a, b, c: so.layer_norm(a, b, c, ctx.layout, ctx.eps), [x, weight, bias], dy)
+            return gx, gw, gb, None, None
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
@@ -129,59 +133,133 @@ def _desc(kind, A, ra, B, ldb, C, rc, bias, M, N, K):
                        0, kind)
 
 
+def _lin_fwd(x, weight, bias, spec):
+    n = x.shape[0]
+    Din, Dout = spec.in_layout.dim, spec.out_layout.dim
+    out = (torch.empty if spec.out_covered else torch.zeros)((n, Dout), device=x.device, dtype=torch.float32)
+    descs = []
+    for (l, in_off, K, out_off, N, w_off) in spec.pairs:
+        d = 2 * l + 1
+        b = bias if (l == 0 and bias is not None) else None
+        descs.append(_desc(0, (x, in_off), rows(d, Din, K), (weight, w_off), N, (out, out_off), rows(d, Dout, N), b,
+                           n * d, N, K))
+    _gemm_group(descs, _stream())
+    return out
+
+
+def _lin_dgrad(dy, weight, spec):
+    n = dy.shape[0]
+    Din, Dout = spec.in_layout.dim, spec.out_layout.dim
+    dx = (torch.empty if spec.in_covered else torch.zeros)((n, Din), device=dy.device, dtype=torch.float32)
+    descs = []
+    for (l, in_off, K, out_off, N, w_off) in spec.pairs:
+        d = 2 * l + 1
+        descs.append(_desc(1, (dy, out_off), rows(d, Dout, N), (weight, w_off), N, (dx, in_off), rows(d, Din, K), None,
+                           n * d, K, N))
+    _gemm_group(descs, _stream())
+    return dx
+
+
+def _lin_wgrad(x, dy, spec, dw):
+    """dw (flat, zero-initialised by the caller) += x^T dy per degree."""
+    n = x.shape[0]
+    Din, Dout = spec.in_layout.dim, spec.out_layout.dim
+    descs = []
+    for (l, in_off, K, out_off, N, w_off) in spec.pairs:
+        d = 2 * l + 1
+        # kind 2: C[K,N] += sum_rows x[row, 0:K]^T dy[row, 0:N]; "rc" describes the dy rows, ldb = ldc
+        descs.append(_desc(2, (x, in_off), rows(d, Din, K), (dy, out_off), N, (dw, w_off), rows(d, Dout, N), None,
+                           K, N, n * d))
+    _gemm_group(descs, _stream())
+    return dw
+
+
+class _LinDgrad(Function):
+    """dx = dy W^T as a differentiable op (used only when the backward runs with create_graph=True)."""
+
+    @staticmethod
+    def forward(ctx, dy, weight, spec):
+        dy, weight = _c(dy), _c(weight)
+        _chk(dy, weight)
+        ctx.save_for_backward(dy, weight)
+        ctx.spec = spec
+        return _lin_dgrad(dy, weight, spec)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c):
+        dy, weight = ctx.saved_tensors
+        c = _c(c)
+        _chk(c)
+        g_dy = _lin_fwd(c, weight, None, ctx.spec) if ctx.needs_input_grad[0] else None
+        g_w = None
+        if ctx.needs_input_grad[1]:
+            g_w = _lin_wgrad(c, dy, ctx.spec, torch.zeros_like(weight))
+        return g_dy, g_w, None
+
+
+class _LinWgrad(Function):
+    """dW = x^T dy as a differentiable op (create_graph only)."""
+
+    @staticmethod
+    def forward(ctx, x, dy, spec):
+        x, dy = _c(x), _c(dy)
+        _chk(x, dy)
+        ctx.save_for_backward(x, dy)
+        ctx.spec = spec
+        return _lin_wgrad(x, dy, spec, torch.zeros(spec.weight_numel, device=x.device, dtype=torch.float32))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c):
+        x, dy = ctx.saved_tensors
+        c = _c(c)
+        _chk(c)
+        g_x = _lin_dgrad(dy, c, ctx.spec) if ctx.needs_input_grad[0] else None
+        g_dy = _lin_fwd(x, c, None, ctx.spec) if ctx.needs_input_grad[1] else None
+        return g_x, g_dy, None
+
+
 class _IrrepsLinear(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, spec):
         x = _c(x)
         weight = _c(weight)
         _chk(x, weight, bias)
-        n = x.shape[0]
-        Din, Dout = spec.in_layout.dim, spec.out_layout.dim
+        Din = spec.in_layout.dim
         assert x.shape[1] == Din and weight.numel() == spec.weight_numel
-        out = (torch.empty if spec.out_covered else torch.zeros)((n, Dout), device=x.device, dtype=torch.float32)
-        descs = []
-        for (l, in_off, K, out_off, N, w_off) in spec.pairs:
-            d = 2 * l + 1
-            b = bias if (l == 0 and bias is not None) else None
-            descs.append(_desc(0, (x, in_off), rows(d, Din, K), (weight, w_off), N, (out, out_off), rows(d, Dout, N), b,
-                               n * d, N, K))
-        _gemm_group(descs, _stream())
+        out = _lin_fwd(x, weight, bias, spec)
         ctx.save_for_backward(x, weight)
         ctx.spec = spec
         ctx.has_bias = bias is not None
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         spec = ctx.spec
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if torch.is_grad_enabled():  # create_graph: every piece is itself differentiable
+            dx = _LinDgrad.apply(dy, weight, spec) if ctx.needs_input_grad[0] else None
+            dw = _LinWgrad.apply(x, dy, spec) if ctx.needs_input_grad[1] else None
+            db = None
+            if want_b:
+                j = spec.out_layout.seg_index(0)
+                o = spec.out_layout.offsets[j]
+                db = dy[:, o:o + spec.bias_dim].sum(0)
+            return dx, dw, db, None
         dy = _c(dy)
         _chk(dy)
         n = x.shape[0]
-        Din, Dout = spec.in_layout.dim, spec.out_layout.dim
+        Dout = spec.out_layout.dim
         st = _stream()
         dx = dw = db = None
-        descs = []
         if ctx.needs_input_grad[0]:
-            dx = (torch.empty if spec.in_covered else torch.zeros)((n, Din), device=x.device, dtype=torch.float32)
-            for (l, in_off, K, out_off, N, w_off) in spec.pairs:
-                d = 2 * l + 1
-                descs.append(_desc(1, (dy, out_off), rows(d, Dout, N), (weight, w_off), N, (dx, in_off), rows(d, Din, K),
-                                   None, n * d, K, N))
-            _gemm_group(descs, st)
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            dx = _lin_dgrad(dy, weight, spec)
         if ctx.needs_input_grad[1] or want_b:
             dw_, db_ = _zeros2(weight.numel(), spec.bias_dim if want_b else 0, x.device)
         if ctx.needs_input_grad[1]:
-            dw = dw_
-            descs = []
-            for (l, in_off, K, out_off, N, w_off) in spec.pairs:
-                d = 2 * l + 1
-                # kind 2: C[K,N] += sum_rows x[row, 0:K]^T dy[row, 0:N]; "rc" describes the dy rows, ldb = ldc
-                descs.append(_desc(2, (x, in_off), rows(d, Din, K), (dy, out_off), N, (dw, w_off), rows(d, Dout, N), None,
-                                   K, N, n * d))
-            _gemm_group(descs, st)
+            dw = _lin_wgrad(x, dy, spec, dw_)
         if want_b:
             db = db_
             j = spec.out_layout.seg_index(0)
@@ -193,6 +271,68 @@ def irreps_linear(x, weight, bias, spec):
     return _IrrepsLinear.apply(x, weight, bias, spec)
 
 
+def _dense_fwd(x, weight, bias):
+    M, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    call("eqf_gemm_nt", _p(x), rows(1, K, 0), _p(weight), K, _p(y), rows(1, N, 0), _p(bias), M, N, K, 0, _stream())
+    return y
+
+
+def _dense_dgrad(dy, weight):
+    M, N = dy.shape
+    K = weight.shape[1]
+    dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    call("eqf_gemm_nn", _p(dy), rows(1, N, 0), _p(weight), K, _p(dx), rows(1, K, 0), None, M, K, N, 0, _stream())
+    return dx
+
+
+def _dense_wgrad(x, dy, dw):
+    """dw [N, K] (zero-initialised) += dy^T x"""
+    M, K = x.shape
+    N = dy.shape[1]
+    call("eqf_gemm_tn", _p(dy), rows(1, N, 0), _p(x), rows(1, K, 0), _p(dw), K, N, K, M, _stream())
+    return dw
+
+
+class _DenseDgrad(Function):
+    @staticmethod
+    def forward(ctx, dy, weight):
+        dy, weight = _c(dy), _c(weight)
+        _chk(dy, weight)
+        ctx.save_for_backward(dy, weight)
+        return _dense_dgrad(dy, weight)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c):
+        dy, weight = ctx.saved_tensors
+        c = _c(c)
+        _chk(c)
+        g_dy = _dense_fwd(c, weight, None) if ctx.needs_input_grad[0] else None
+        g_w = _dense_wgrad(c, dy, torch.zeros_like(weight)) if ctx.needs_input_grad[1] else None
+        return g_dy, g_w
+
+
+class _DenseWgrad(Function):
+    @staticmethod
+    def forward(ctx, x, dy):
+        x, dy = _c(x), _c(dy)
+        _chk(x, dy)
+        ctx.save_for_backward(x, dy)
+        return _dense_wgrad(x, dy, torch.zeros((dy.shape[1], x.shape[1]), device=x.device, dtype=torch.float32))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c):
+        x, dy = ctx.saved_tensors
+        c = _c(c)
+        _chk(c)
+        g_x = _dense_dgrad(dy, c) if ctx.needs_input_grad[0] else None
+        g_dy = _dense_fwd(x, c, None) if ctx.needs_input_grad[1] else None
+        return g_x, g_dy
+
+
 class _DenseLinear(Function):
     """torch.nn.Linear semantics (y = x W^T + b) on the exact-fp32 MFMA path."""
 
@@ -201,18 +341,20 @@ class _DenseLinear(Function):
         x = _c(x)
         weight = _c(weight)
         _chk(x, weight, bias)
-        M, K = x.shape
-        N = weight.shape[0]
-        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-        call("eqf_gemm_nt", _p(x), rows(1, K, 0), _p(weight), K, _p(y), rows(1, N, 0), _p(bias), M, N, K, 0, _stream())
+        y = _dense_fwd(x, weight, bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if torch.is_grad_enabled():  # create_graph
+            dx = _DenseDgrad.apply(dy, weight) if ctx.needs_input_grad[0] else None
+            dw = _DenseWgrad.apply(x, dy) if ctx.needs_input_grad[1] else None
+            db = dy.sum(0) if want_b else None
+            return dx, dw, db
         dy = _c(dy)
         _chk(dy)
         M, K = x.shape
@@ -220,14 +362,11 @@ class _DenseLinear(Function):
         st = _stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            call("eqf_gemm_nn", _p(dy), rows(1, N, 0), _p(weight), K, _p(dx), rows(1, K, 0), None, M, K, N, 0, st)
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            dx = _dense_dgrad(dy, weight)
         if ctx.needs_input_grad[1] or want_b:
             dw_, db_ = _zeros2(weight.numel(), N if want_b else 0, x.device)
         if ctx.needs_input_grad[1]:
-            dw = dw_.view_as(weight)
-            call("eqf_gemm_tn", _p(dy), rows(1, N, 0), _p(x), rows(1, K, 0), _p(dw), K, N, K, M, st)
+            dw = _dense_wgrad(x, dy, dw_.view_as(weight))
         if want_b:
             db = db_
             call("eqf_colsum", _p(dy), rows(1, N, 0), M, N, _p(db), st)
@@ -255,10 +394,12 @@ class _Gate(Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         S, gated_layout, c_silu, c_sig = ctx.args
+        if torch.is_grad_enabled():  # create_graph
+            (gx,) = so.vjp(lambda a: so.gate(a, S, gated_layout, c_silu, c_sig), [x], dy)
+            return gx, None, None, None, None
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
@@ -282,9 +423,11 @@ class _ScaledSilu(Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
+        if torch.is_grad_enabled():  # create_graph
+            (gx,) = so.vjp(lambda a: so.scaled_silu(a, ctx.c), [x], dy)
+            return gx, None
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
@@ -308,9 +451,11 @@ class _LnSilu(Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         x, gamma, beta = ctx.saved_tensors
+        if torch.is_grad_enabled():  # create_graph
+            gx, gg, gb = so.vjp(lambda a, b, c: so.ln_silu(a, b, c, ctx.eps), [x, gamma, beta], dy)
+            return gx, gg, gb, None
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
@@ -356,41 +501,107 @@ def embed(types, W, b, D):
 
 
 # ------------------------------------------------------------------------------------------------- graph ops
+def _gather_add_fwd(a, b, graph):
+    D = a.shape[1]
+    msg = torch.empty((graph.E, D), device=a.device, dtype=torch.float32)
+    call("eqf_gather_add_fwd", _p(a), _p(b), _p(graph.src), _p(graph.dst), _p(msg), graph.E, D, _stream())
+    return msg
+
+
+def _gather_add_bwd(dmsg, g, n, want_a, want_b):
+    D = dmsg.shape[1]
+    st = _stream()
+    da = db = None
+    if want_a:
+        da = torch.empty((n, D), device=dmsg.device, dtype=torch.float32)
+        call("eqf_segment_sum", _p(dmsg), _p(g.src_ptr), _p(g.src_perm), _p(da), n, D, 1.0, 0, st)
+    if want_b:
+        db = torch.empty((n, D), device=dmsg.device, dtype=torch.float32)
+        call("eqf_segment_sum", _p(dmsg), _p(g.row_ptr), None, _p(db), n, D, 1.0, 0, st)
+    return da, db
+
+
+class _GatherAddBwd(Function):
+    """(da, db) = adjoint of msg = a[src] + b[dst], as a differentiable (linear) op; create_graph only."""
+
+    @staticmethod
+    def forward(ctx, dmsg, graph, n, has_b):
+        dmsg = _c(dmsg)
+        _chk(dmsg)
+        ctx.graph, ctx.has_b = graph, has_b
+        da, db = _gather_add_bwd(dmsg, graph, n, True, has_b)
+        if has_b:
+            return da, db
+        return da
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ca, cb=None):
+        ca = _c(ca) if ca is not None else None
+        cb = _c(cb) if cb is not None else None
+        if ca is None and cb is None:
+            return None, None, None, None
+        if ca is None:
+            ca = torch.zeros_like(cb)
+        _chk(ca, cb)
+        return _gather_add_fwd(ca, cb, ctx.graph), None, None, None
+
+
 class _GatherAdd(Function):
     @staticmethod
     def forward(ctx, a, b, graph):
         a = _c(a)
         b = _c(b) if b is not None else None
         _chk(a, b)
-        D = a.shape[1]
-        msg = torch.empty((graph.E, D), device=a.device, dtype=torch.float32)
-        call("eqf_gather_add_fwd", _p(a), _p(b), _p(graph.src), _p(graph.dst), _p(msg), graph.E, D, _stream())
+        msg = _gather_add_fwd(a, b, graph)
         ctx.graph = graph
         ctx.has_b = b is not None
         ctx.n = a.shape[0]
         return msg
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dmsg):
         g = ctx.graph
+        if torch.is_grad_enabled():  # create_graph
+            if ctx.has_b:
+                da, db = _GatherAddBwd.apply(dmsg, g, ctx.n, True)
+                return da, db, None
+            return _GatherAddBwd.apply(dmsg, g, ctx.n, False), None, None
         dmsg = _c(dmsg)
         _chk(dmsg)
-        D = dmsg.shape[1]
-        st = _stream()
-        da = db = None
-        if ctx.needs_input_grad[0]:
-            da = torch.empty((ctx.n, D), device=dmsg.device, dtype=torch.float32)
-            call("eqf_segment_sum", _p(dmsg), _p(g.src_ptr), _p(g.src_perm), _p(da), ctx.n, D, 1.0, 0, st)
-        if ctx.has_b and ctx.needs_input_grad[1]:
-            db = torch.empty((ctx.n, D), device=dmsg.device, dtype=torch.float32)
-            call("eqf_segment_sum", _p(dmsg), _p(g.row_ptr), None, _p(db), ctx.n, D, 1.0, 0, st)
+        da, db = _gather_add_bwd(dmsg, g, ctx.n, ctx.needs_input_grad[0], ctx.has_b and ctx.needs_input_grad[1])
         return da, db, None
 
 
 def gather_add(a, b, graph):
     """msg[e] = a[src[e]] + b[dst[e]]  (b may be None)."""
     return _GatherAdd.apply(a, b, graph)
+
+
+class _SegmentBcast(Function):
+    """dx[q] = scale * dout[seg_of[q]] as a differentiable (linear) op; create_graph only."""
+
+    @staticmethod
+    def forward(ctx, dout, seg_of, ptr, n, scale):
+        dout = _c(dout)
+        _chk(dout)
+        D = dout.shape[1]
+        dx = torch.empty((n, D), device=dout.device, dtype=torch.float32)
+        call("eqf_segment_bcast", _p(dout), _p(seg_of), _p(dx), n, D, scale, _stream())
+        ctx.save_for_backward(ptr)
+        ctx.args = (dout.shape[0], D, scale)
+        return dx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c):
+        (ptr,) = ctx.saved_tensors
+        nseg, D, scale = ctx.args
+        c = _c(c)
+        _chk(c)
+        out = torch.empty((nseg, D), device=c.device, dtype=torch.float32)
+        call("eqf_segment_sum", _p(c), _p(ptr), None, _p(out), nseg, D, scale, 0, _stream())
+        return out, None, None, None, None
 
 
 class _SegmentSum(Function):
@@ -401,15 +612,16 @@ class _SegmentSum(Function):
         D = x.shape[1]
         out = torch.empty((nseg, D), device=x.device, dtype=torch.float32)
         call("eqf_segment_sum", _p(x), _p(ptr), None, _p(out), nseg, D, scale, 0, _stream())
-        ctx.save_for_backward(seg_of)
+        ctx.save_for_backward(seg_of, ptr)
         ctx.args = (x.shape[0], D, scale)
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
-        (seg_of,) = ctx.saved_tensors
+        seg_of, ptr = ctx.saved_tensors
         n, D, scale = ctx.args
+        if torch.is_grad_enabled():  # create_graph
+            return _SegmentBcast.apply(dout, seg_of, ptr, n, scale), None, None, None, None
         dout = _c(dout)
         _chk(dout)
         dx = torch.empty((n, D), device=dout.device, dtype=torch.float32)
@@ -425,6 +637,7 @@ def segment_sum(x, ptr, seg_of, nseg, scale=1.0):
 class _EdgeGeom(Function):
     @staticmethod
     def forward(ctx, pos, offsets, graph, lmax):
+        pos_in = pos
         pos = _c(pos)
         _chk(pos, offsets)
         E = graph.E
@@ -433,16 +646,19 @@ class _EdgeGeom(Function):
         sh = torch.empty((E, (lmax + 1) ** 2), device=pos.device, dtype=torch.float32)
         call("eqf_edge_geom_fwd", _p(pos), _p(graph.src), _p(graph.dst), _p(offsets), E, lmax, _p(vec), _p(length),
              _p(sh), _stream())
-        ctx.save_for_backward(vec)
+        ctx.save_for_backward(vec, pos_in)
         ctx.graph, ctx.lmax, ctx.n = graph, lmax, pos.shape[0]
+        ctx.offsets = offsets
         ctx.mark_non_differentiable(vec)
         return vec, length, sh
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, _dvec, dlen, dsh):
-        (vec,) = ctx.saved_tensors
+        vec, pos_in = ctx.saved_tensors
         g = ctx.graph
+        if torch.is_grad_enabled():  # create_graph
+            (gpos,) = so.vjp(lambda p: so.edge_geometry(p, ctx.offsets, g, ctx.lmax), [pos_in], (dlen, dsh))
+            return gpos, None, None, None
         dlen = _c(dlen) if dlen is not None else None
         dsh = _c(dsh) if dsh is not None else None
         _chk(dlen, dsh)
@@ -504,11 +720,13 @@ class _RbfExpNorm(Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
         length, means, betas = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
             return None, None, None, None, None
+        if torch.is_grad_enabled():  # create_graph
+            (gl,) = so.vjp(lambda a: so.rbf_expnorm(a, means, betas, ctx.args[0], ctx.args[1]), [length], dout)
+            return gl, None, None, None, None
         dout = _c(dout)
         _chk(dout)
         dlen = torch.empty_like(length)
@@ -522,26 +740,53 @@ def rbf_expnorm(length, means, betas, alpha, cutoff):
 
 
 # ------------------------------------------------------------------------------------------------- DTP
+def _coupling_fwd(sh, table):
+    E = sh.shape[0]
+    M = torch.empty((E, table.m_numel), device=sh.device, dtype=torch.float32)
+    call("eqf_dtp_coupling_fwd", _p(sh), _p(table.cg(sh.device)), table.c_ref, _p(M), E, _stream())
+    return M
+
+
+def _coupling_bwd(dM, table, shape):
+    dsh = torch.empty(shape, device=dM.device, dtype=torch.float32)
+    call("eqf_dtp_coupling_bwd", _p(dM), _p(table.cg(dM.device)), table.c_ref, _p(dsh), shape[0], _stream())
+    return dsh
+
+
+class _CouplingBwd(Function):
+    """d_sh from d_coupling as a differentiable (linear) op; create_graph only."""
+
+    @staticmethod
+    def forward(ctx, dM, table, shape):
+        dM = _c(dM)
+        _chk(dM)
+        ctx.table = table
+        return _coupling_bwd(dM, table, shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c):
+        c = _c(c)
+        _chk(c)
+        return _coupling_fwd(c, ctx.table), None, None
+
+
 class _Coupling(Function):
     @staticmethod
     def forward(ctx, sh, table):
         sh = _c(sh)
         _chk(sh)
-        E = sh.shape[0]
-        M = torch.empty((E, table.m_numel), device=sh.device, dtype=torch.float32)
-        call("eqf_dtp_coupling_fwd", _p(sh), _p(table.cg(sh.device)), table.c_ref, _p(M), E, _stream())
+        M = _coupling_fwd(sh, table)
         ctx.table, ctx.shape = table, sh.shape
         return M
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dM):
+        if torch.is_grad_enabled():  # create_graph
+            return _CouplingBwd.apply(dM, ctx.table, ctx.shape), None
         dM = _c(dM)
         _chk(dM)
-        dsh = torch.empty(ctx.shape, device=dM.device, dtype=torch.float32)
-        call("eqf_dtp_coupling_bwd", _p(dM), _p(ctx.table.cg(dM.device)), ctx.table.c_ref, _p(dsh), ctx.shape[0],
-             _stream())
-        return dsh, None
+        return _coupling_bwd(dM, ctx.table, ctx.shape), None
 
 
 def dtp_coupling(sh, table):
@@ -711,6 +956,112 @@ def _ptr_array(pairs):
     return arr
 
 
+class _Guard(Function):
+    """Identity whose backward raises: marks a first-order result that must not be differentiated again."""
+
+    @staticmethod
+    def forward(ctx, t, dep, what):
+        ctx.what = what
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("second-order differentiation through the %s is not implemented" % ctx.what)
+
+
+def _guard(t, dep, what):
+    return _Guard.apply(t, dep, what) if dep.requires_grad else t
+
+
+def _sfc_fwd(x, coupling, w, weight, bias, weight2, bias2, spec):
+    E = x.shape[0]
+    out1 = torch.empty((E, spec.out_layout.dim), device=x.device, dtype=torch.float32)
+    out2 = torch.empty((E, spec.n2), device=x.device, dtype=torch.float32) if spec.n2 else None
+    Wl = _ptr_array((l3, weight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
+    call("eqf_sfc_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(bias), _p(weight2), _p(bias2), _p(out1),
+         spec.out_layout.c_ref, _p(out2), spec.n2, E, _stream())
+    return out1, out2
+
+
+def _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, want_dM):
+    E = x.shape[0]
+    dx = (torch.empty_like if spec.in_covered else torch.zeros_like)(x)
+    dw = torch.empty_like(w) if w is not None else None
+    dM = torch.zeros_like(coupling) if want_dM else None
+    Wl = _ptr_array((l3, weight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
+    call("eqf_sfc_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(weight2), _p(d1),
+         spec.out_layout.c_ref, _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, _stream())
+    return dx, dM, dw
+
+
+def _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2):
+    """dweight (flat) / dweight2, zero-initialised by the caller, are accumulated into."""
+    dWl = _ptr_array((l3, dweight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
+    call("eqf_sfc_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref, _p(d2),
+         spec.n2, dWl, _p(dweight2), x.shape[0], _stream())
+
+
+class _SepFctpBwdData(Function):
+    """(dx, d_coupling, dw) of the fused SeparableFCTP as a differentiable op (create_graph only).  Phi(x, M, w, W, g) =
+    <g, F(x, M, w, W)> is multilinear, so the pairing with cotangents (cx, cM, cw) is
+    Psi = Phi(cx, M, w, W, g) + Phi(x, cM, w, W, g) + Phi(x, M, cw, W, g) and every gradient of Psi is one of the
+    first-order kernels (forward, data-gradient, weight-gradient) evaluated with one argument substituted."""
+
+    @staticmethod
+    def forward(ctx, x, coupling, w, weight, weight2, d1, d2, spec):
+        x, coupling, weight, d1 = _c(x), _c(coupling), _c(weight), _c(d1)
+        w = _c(w) if w is not None else None
+        weight2 = _c(weight2) if weight2 is not None else None
+        d2 = _c(d2) if d2 is not None else None
+        _chk(x, coupling, w, weight, weight2, d1, d2)
+        ctx.save_for_backward(x, coupling, w, weight, weight2, d1, d2)
+        ctx.spec = spec
+        dx, dM, dw = _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, True)
+        if w is None:
+            return dx, dM
+        return dx, dM, dw
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, cx, cM, cw=None):
+        x, M, w, weight, weight2, d1, d2 = ctx.saved_tensors
+        spec = ctx.spec
+        need = ctx.needs_input_grad  # x, M, w, weight, weight2, d1, d2
+        g_x = g_M = g_w = g_W = g_W2 = g_d1 = g_d2 = None
+
+        def acc(a, b):
+            if b is None:
+                return a
+            return b if a is None else a + b
+
+        if need[3] or (weight2 is not None and need[4]):
+            g_W = torch.zeros_like(weight)
+            g_W2 = torch.zeros_like(weight2) if weight2 is not None else None
+        subs = []
+        if cx is not None:
+            subs.append((_c(cx), M, w, "x"))
+        if cM is not None:
+            subs.append((x, _c(cM), w, "M"))
+        if cw is not None and w is not None:
+            subs.append((x, M, _c(cw), "w"))
+        for (xs, Ms, ws, which) in subs:
+            _chk(xs, Ms, ws)
+            if need[5] or need[6]:
+                o1, o2 = _sfc_fwd(xs, Ms, ws, weight, None, weight2, None, spec)
+                g_d1, g_d2 = acc(g_d1, o1), acc(g_d2, o2)
+            if need[0] or need[1] or need[2]:
+                dx_, dM_, dw_ = _sfc_bwd_data(xs, Ms, ws, weight, weight2, d1, d2, spec, which != "M" and need[1])
+                if which != "x" and need[0]:
+                    g_x = acc(g_x, dx_)
+                if which != "M" and need[1]:
+                    g_M = acc(g_M, dM_)
+                if which != "w" and w is not None and need[2]:
+                    g_w = acc(g_w, dw_)
+            if g_W is not None:
+                _sfc_bwd_weight(xs, Ms, ws, d1, d2, spec, g_W, g_W2)
+        return g_x, g_M, g_w, g_W, g_W2, g_d1, g_d2, None
+
+
 class _SepFctp(Function):
     """weight: flat [sum_l K(l) N1(l)] (e3nn LinearRS layout: one [K(l), N1(l)] block per degree, ascending);
     weight2: flat [K(0) n2] or None.  The kernels read the blocks in place (no slicing / concatenation on the host)."""
@@ -737,13 +1088,38 @@ class _SepFctp(Function):
         return out1, out2
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, d1, d2=None):
         x, coupling, w, weight, weight2 = ctx.saved_tensors
         spec = ctx.spec
         E = x.shape[0]
         st = _stream()
         dev = x.device
+        if torch.is_grad_enabled():  # create_graph: differentiable data-gradient (forces); see _SepFctpBwdData
+            need = ctx.needs_input_grad
+            if d1 is None:
+                d1 = torch.zeros((E, spec.out_layout.dim), device=dev, dtype=torch.float32)
+            if spec.n2 and d2 is None:
+                d2 = torch.zeros((E, spec.n2), device=dev, dtype=torch.float32)
+            outs = _SepFctpBwdData.apply(x, coupling, w, weight, weight2, d1, d2 if spec.n2 else None, spec)
+            dx, dM = outs[0], outs[1]
+            dw = outs[2] if w is not None else None
+            # needs_input_grad is static (the parameters always "need" a gradient), so the weight / bias gradients
+            # are produced here as well -- first-order kernels, guarded: differentiating THROUGH them is not implemented
+            gW = gb = gW2 = gb2 = None
+            if need[3] or need[5]:
+                with torch.no_grad():
+                    gW_ = torch.zeros_like(weight)
+                    gW2_ = torch.zeros_like(weight2) if weight2 is not None else None
+                    _sfc_bwd_weight(x, coupling, w, _c(d1), _c(d2) if spec.n2 else None, spec, gW_, gW2_)
+                gW = _guard(gW_, d1, "weight gradient of the fused SeparableFCTP")
+                gW2 = _guard(gW2_, d1, "weight gradient of the fused SeparableFCTP") if gW2_ is not None else None
+            if ctx.has_bias[0] and need[4]:
+                j = spec.out_layout.seg_index(0)
+                o = spec.out_layout.offsets[j]
+                gb = d1[:, o:o + spec.out_layout.mul_of(0)].sum(0)
+            if ctx.has_bias[1] and need[6]:
+                gb2 = d2.sum(0)
+            return dx, dM, dw, gW, gb, gW2, gb2, None
         if d1 is None:
             d1 = torch.zeros((E, spec.out_layout.dim), device=dev, dtype=torch.float32)
         if spec.n2 and d2 is None:
@@ -804,10 +1180,12 @@ class _AlphaLogits(Function):
         return logit
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dlogit):
         a, alpha_dot = ctx.saved_tensors
         H, Kh, c = ctx.args
+        if torch.is_grad_enabled():  # create_graph
+            ga, gd = so.vjp(lambda u, v: so.alpha_logits(u, v, H, Kh, c), [a, alpha_dot], dlogit)
+            return ga, gd, None, None, None
         dlogit = _c(dlogit)
         _chk(dlogit)
         da = torch.empty_like(a)
@@ -830,15 +1208,19 @@ class _AttnAggregate(Function):
         out = torch.empty((N, layout.dim), device=value.device, dtype=torch.float32)
         call("eqf_attn_aggregate_fwd", _p(logit), _p(value), _p(graph.row_ptr), _p(alpha), _p(out), N, H, layout.c_ref,
              drop_p, seed, _stream())
-        ctx.save_for_backward(alpha, value)
+        ctx.save_for_backward(alpha, value, logit)
         ctx.args = (graph, H, layout, drop_p, seed)
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
-        alpha, value = ctx.saved_tensors
+        alpha, value, logit = ctx.saved_tensors
         graph, H, layout, drop_p, seed = ctx.args
+        if torch.is_grad_enabled():  # create_graph
+            if drop_p > 0.0:
+                raise NotImplementedError("second-order attention with alpha_drop > 0 (every MD17 config has alpha_drop = 0)")
+            gl, gv = so.vjp(lambda u, v: so.attn_aggregate(u, v, graph, H, layout), [logit, value], dout)
+            return gl, gv, None, None, None, None, None
         dout = _c(dout)
         _chk(dout)
         dvalue = torch.empty_like(value)

@@ -137,3 +137,42 @@ def test_oc20_energy_parity():
     y = mod(data)
     print("oc20 energy rel %.3e (E=%d edges)" % (_rel(y, yr), src.numel()))
     assert _rel(y, yr) < 1e-4
+
+
+def test_md17_force_loss_second_order_gradients():
+    """Training on the force loss (reference: main_md17.py:384-390 with create_graph forces): gradients of
+    L = <a, E> + <B, F> w.r.t. every parameter against the fp64 oracle's double backward, reduced MD17-L2 model with
+    deterministic weights (tests/golden/weights.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+    from weights import fill_deterministic
+    from equiformer_amd.nets.graph_attention_transformer_md17 import GraphAttentionTransformerMD17
+    from equiformer_amd.synthetic import md17_aspirin_batch
+    dev = _dev()
+    kw = dict(irreps_in="64x0e", max_radius=5.0, number_of_basis=32, basis_type="exp", **mg.SMALL_L2)
+    ref = fill_deterministic(onets.GraphAttentionTransformerMD17(**kw), 12).double().train()
+    mod = fill_deterministic(GraphAttentionTransformerMD17(**kw), 12).to(dev).train()
+    d = md17_aspirin_batch(2, seed=3)
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(2, 1, generator=g, dtype=torch.float64)
+    B = torch.randn(42, 3, generator=g, dtype=torch.float64)
+    Er, Fr = ref(d["z"], d["pos"].double(), d["batch"])
+    Lr = (a * Er).sum() + (B * Fr).sum()
+    gr = torch.autograd.grad(Lr, list(ref.parameters()), allow_unused=True)
+    E, F = mod(d["z"].to(dev), d["pos"].to(dev), d["batch"].to(dev))
+    assert F.requires_grad, "training-mode forces must carry a graph"
+    L = (a.float().to(dev) * E).sum() + (B.float().to(dev) * F).sum()
+    gg = torch.autograd.grad(L, list(mod.parameters()), allow_unused=True)
+    assert _rel(E, Er) < 1e-4 and _rel(F, Fr) < 1e-4
+    worst = ("", 0.0)
+    for (n, _), x, r in zip(ref.named_parameters(), gg, gr):
+        if r is None or r.abs().max() == 0:
+            continue
+        assert x is not None, n
+        e = _rel(x, r)
+        if e > worst[1]:
+            worst = (n, e)
+    print("worst second-order gradient error: %s %.3e" % worst)
+    assert worst[1] < 2e-3, worst
