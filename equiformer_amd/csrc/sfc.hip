@@ -33,6 +33,10 @@ extern __shared__ __attribute__((aligned(16))) float sfc_lds[];  // dynamic LDS 
 namespace {
 
 unsigned long long* g_sfc_dbg = nullptr;  // set by eqf_sfc_debug_buffer (development aid)
+// workgroup ordering per kernel {fwd, bwd_data, bwd_weight}, see SfcOrder; measured (MI355X, E = 25 354): order 1 is
+// 8-12 % faster for bwd_weight, 0-6 % for bwd_data, and 0-14 % SLOWER for fwd (its workgroups of one degree share the
+// staged weight slabs, which the degree-major order keeps hot).  eqf_sfc_debug_order overrides all three for A/B runs.
+int g_sfc_order[3] = {0, 1, 1};
 
 constexpr int SFC_MAX_DEG = 4;
 constexpr int SFC_MAX_SLABS = 72;   // 32-channel slabs over all output degrees (DTP width <= 3072 channels)
@@ -73,6 +77,35 @@ struct SfcCommon {
   SfcSlab slab[SFC_MAX_SLABS];
 };
 
+// Workgroup ordering.  All three kernels launch a 1-D grid of nx * ny workgroups, where the ny workgroups that share
+// an x (an edge tile / edge chunk) re-read the same rows of x, w, coupling and d_out.  The hardware deals consecutive
+// workgroup ids round-robin over the 8 XCDs, each with its own L2, so with order 1 the launch id b is first turned
+// into a logical id that runs fastest *inside* an XCD (b % 8 = XCD, b / 8 = position), and logical neighbours -- the ny
+// sharers of one x -- land on the same L2 at about the same time: their re-reads are L2 hits instead of trips to
+// HBM / infinity cache.  order 0 = plain x-fastest enumeration (first version), order 2 = y-fastest without the XCD
+// step (kept for A/B measurements).
+struct SfcOrder {
+  int mode, nx, ny, per_xcd;
+};
+__host__ inline SfcOrder make_order(int kernel, int nx, int ny, int& nblocks) {
+  SfcOrder o;
+  o.mode = g_sfc_order[kernel], o.nx = nx, o.ny = ny;
+  o.per_xcd = (nx * ny + 7) / 8;
+  nblocks = (o.mode == 1) ? 8 * o.per_xcd : nx * ny;
+  return o;
+}
+// false: surplus workgroup of the padded grid
+__device__ __forceinline__ bool order_xy(const SfcOrder& o, int b, int& x, int& y) {
+  if (o.mode == 0) {
+    y = b / o.nx, x = b - y * o.nx;
+    return true;
+  }
+  const int L = (o.mode == 1) ? (b & 7) * o.per_xcd + (b >> 3) : b;
+  if (L >= o.nx * o.ny) return false;
+  x = L / o.ny, y = L - x * o.ny;
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // These kernels are instruction-issue bound unless every small loop is unrolled with compile-time trip counts (the
 // first, runtime-indexed version spent 23 VALU + 10 SALU instructions per MFMA): the bodies are therefore templated
@@ -99,7 +132,9 @@ struct SfcFwdArgs {
   const float* bias;   // [N1 of degree 0] or null
   const float* bias2;  // [N2] or null
   unsigned long long* dbg;  // optional phase timers (development aid), may be null
-  int nsplit[SFC_MAX_DEG], cps[SFC_MAX_DEG], blk0[SFC_MAX_DEG + 1];
+  int nsplit[SFC_MAX_DEG], cps[SFC_MAX_DEG];
+  SfcOrder ord;                                // nx = edge tiles, ny = (degree, column split) pairs
+  signed char y_deg[16], y_split[16];
 };
 
 template <int D3, int NT, int FT>
@@ -329,9 +364,10 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
 
 template <int MAXD>
 __global__ __launch_bounds__(256, (MAXD <= 5 ? 2 : 1)) void sfc_fwd_kernel(const SfcFwdArgs g) {
-  int b = blockIdx.x, di = 0;
-  while (di + 1 < g.c.ndeg && b >= g.blk0[di + 1]) ++di;
-  b -= g.blk0[di];
+  int tile, y;
+  if (!order_xy(g.ord, blockIdx.x, tile, y)) return;
+  const int di = g.y_deg[y];
+  const int b = tile * g.nsplit[di] + g.y_split[y];
   switch (g.c.deg[di].d3) {
     case 1: f_block<1, MAXD>(g, di, b); break;
     case 3: f_block<3, MAXD>(g, di, b); break;
@@ -347,6 +383,7 @@ struct SfcWgArgs {
   SfcCommon c;
   int nitem;
   int echunk;  // edges per workgroup (multiple of 8)
+  SfcOrder ord;  // nx = edge chunks, ny = items
   short item_slab[2 * SFC_MAX_SLABS];  // global index of the group's first slab
   short item_ns[2 * SFC_MAX_SLABS];    // slabs in the group (1..4)
   short item_cls[2 * SFC_MAX_SLABS];   // compile-time tile count of the item's body: 1, 2, 4 or 8
@@ -451,7 +488,8 @@ __device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, co
 // group over the WHOLE chunk, so the four waves stream the same d_out rows at the same time (one HBM fetch, three L1 /
 // L2 hits) and every wave finishes with its own [32 x CTT*32] block of the weight gradient -- no cross-wave reduction.
 template <int CTT, int MAXD>
-__device__ __forceinline__ void wg_item(const SfcWgArgs& g, const int item, float (&Msh)[4][W_SUB * MAXD * MAXD]) {
+__device__ __forceinline__ void wg_item(const SfcWgArgs& g, const int item, const int chunk,
+                                        float (&Msh)[4][W_SUB * MAXD * MAXD]) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave >= g.item_ns[item]) return;  // a group of fewer than 4 slabs
   const int slab = g.item_slab[item] + wave;
@@ -459,7 +497,7 @@ __device__ __forceinline__ void wg_item(const SfcWgArgs& g, const int item, floa
   const SfcDeg& D = g.c.deg[S.deg];
   const int col0 = g.item_col0[item], CT = g.item_ct[item];
   const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
-  const int ebeg = blockIdx.x * g.echunk;
+  const int ebeg = chunk * g.echunk;
   const int eend = min(g.c.E, ebeg + g.echunk);
   if (ebeg >= eend) return;
 
@@ -521,12 +559,13 @@ __global__ __launch_bounds__(256, 2) void sfc_wgrad_kernel(const SfcWgArgs g_byv
   const SfcWgArgs& g = g_byval;
 #endif
   __shared__ float Msh[4][W_SUB * MAXD * MAXD];  // per wave: [edge][i*d3 + m3] of the slab's path
-  const int item = blockIdx.y;
+  int chunk, item;
+  if (!order_xy(g.ord, blockIdx.x, chunk, item)) return;
   switch (g.item_cls[item]) {
-    case 8: wg_item<8, MAXD>(g, item, Msh); break;
-    case 4: wg_item<4, MAXD>(g, item, Msh); break;
-    case 2: wg_item<2, MAXD>(g, item, Msh); break;
-    default: wg_item<1, MAXD>(g, item, Msh); break;
+    case 8: wg_item<8, MAXD>(g, item, chunk, Msh); break;
+    case 4: wg_item<4, MAXD>(g, item, chunk, Msh); break;
+    case 2: wg_item<2, MAXD>(g, item, chunk, Msh); break;
+    default: wg_item<1, MAXD>(g, item, chunk, Msh); break;
   }
 }
 
@@ -558,6 +597,7 @@ struct SfcBwdArgs {
   int ngrp;
   int dt_floats;  // LDS partition
   int full_m;     // the LDS coupling block holds whole coupling rows (mt_len == m_ld, mt_off == m_off)
+  SfcOrder ord;   // nx = edge tiles, ny = chunk groups
   unsigned long long* dbg;  // optional phase timers (cycles of wave 0 / lane 0 of every workgroup), may be null
   SfcBGroup grp[B_MAXGRP];
 };
@@ -567,10 +607,11 @@ struct SfcBwdArgs {
 // v_mfma_f32_16x16x4_f32; its accumulator layout (lane = channel, 4 edges per lane) is exactly what the DTP backward
 // contraction wants, so the epilogue runs in registers: no exchange of d_mid between waves at all.
 template <int D1, int CG, int MAXD>
-__device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G, float* __restrict__ smem) {
+__device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G, const int tile,
+                                        float* __restrict__ smem) {
   float* __restrict__ Dt = smem;                // [k][32*d3 + 4]
   float* __restrict__ Mt = smem + g.dt_floats;  // [32][mt_len]
-  const int e0 = blockIdx.x * B_TE;
+  const int e0 = tile * B_TE;
   const int ecnt = min(B_TE, g.c.E - e0);
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -826,15 +867,17 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
 // grid packs the CUs much better than one launch per flavour (measured: 3 launches of 793 workgroups were 25 % slower).
 template <int MAXD>
 __global__ __launch_bounds__(256, (MAXD <= 5 ? 2 : 1)) void sfc_bwd_kernel(const SfcBwdArgs g) {
-  const SfcBGroup& G = g.grp[blockIdx.y];
+  int tile, gi;
+  if (!order_xy(g.ord, blockIdx.x, tile, gi)) return;
+  const SfcBGroup& G = g.grp[gi];
   switch (G.d1) {
     case 1:
-      if (G.nch == 2) b_block<1, 2, MAXD>(g, G, sfc_lds);
-      else b_block<1, 1, MAXD>(g, G, sfc_lds);
+      if (G.nch == 2) b_block<1, 2, MAXD>(g, G, tile, sfc_lds);
+      else b_block<1, 1, MAXD>(g, G, tile, sfc_lds);
       break;
-    case 3: b_block<3, 1, MAXD>(g, G, sfc_lds); break;
-    case 5: b_block<(MAXD >= 5 ? 5 : 1), 1, MAXD>(g, G, sfc_lds); break;
-    default: b_block<(MAXD >= 7 ? 7 : 1), 1, MAXD>(g, G, sfc_lds); break;
+    case 3: b_block<3, 1, MAXD>(g, G, tile, sfc_lds); break;
+    case 5: b_block<(MAXD >= 5 ? 5 : 1), 1, MAXD>(g, G, tile, sfc_lds); break;
+    default: b_block<(MAXD >= 7 ? 7 : 1), 1, MAXD>(g, G, tile, sfc_lds); break;
   }
 }
 
@@ -929,6 +972,13 @@ extern "C" {
 
 /* development aid (not declared in the public header): 8 x u64 device counters the data-gradient kernel adds its
  * per-phase cycle counts to; NULL disables */
+int eqf_sfc_debug_order(int mode) {
+  if (mode < -1 || mode > 2) return EQF_E_BADARG;
+  g_sfc_order[0] = mode < 0 ? 0 : mode;  // -1: defaults
+  g_sfc_order[1] = g_sfc_order[2] = mode < 0 ? 1 : mode;
+  return 0;
+}
+
 int eqf_sfc_debug_buffer(void* p) {
   g_sfc_dbg = (unsigned long long*)p;
   return 0;
@@ -950,8 +1000,7 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
   const int ft = md <= 5 ? 3 : F_MAXT;
   const int ntile = eqf_cdiv(E, F_TE);
   size_t lds = 0;
-  int blk = 0;
-  // heaviest degrees first (their workgroups take longest)
+  int ny = 0;
   for (int d = 0; d < A.c.ndeg; ++d) {
     const SfcDeg& D = A.c.deg[d];
     if (!D.W) return EQF_E_BADARG;
@@ -962,13 +1011,17 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
     const int cttot = D.Ncat / 32;
     A.nsplit[d] = eqf_cdiv(cttot, maxct);
     A.cps[d] = eqf_cdiv(cttot, A.nsplit[d]) * 32;
-    A.blk0[d] = blk;
-    blk += ntile * A.nsplit[d];
+    for (int k = 0; k < A.nsplit[d]; ++k) {
+      if (ny >= 16) return EQF_E_UNSUPPORTED;
+      A.y_deg[ny] = (signed char)d, A.y_split[ny] = (signed char)k;
+      ++ny;
+    }
     const size_t need = sizeof(float) * (32 * (F_TE * D.d3 + 1) + 32 * f_sb(D.d3, ft) + (size_t)F_TE * D.m_len);
     if (need > lds) lds = need;
   }
-  A.blk0[A.c.ndeg] = blk;
   if (lds > SFC_LDS_LIMIT) return EQF_E_UNSUPPORTED;
+  int blk = 0;
+  A.ord = make_order(0, ntile, ny, blk);
 
   hipStream_t st = (hipStream_t)stream;
   const int pid = eqf_prof_begin("sfc_fwd", st, sfc_flops(A.c), sfc_bytes(A.c));
@@ -1045,7 +1098,9 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
     if (echunk < 128) echunk = 128;
     A.echunk = echunk;
     z = eqf_cdiv(E, echunk);
-    dim3 grid(z, A.nitem);
+    int nblk = 0;
+    A.ord = make_order(2, z, A.nitem, nblk);
+    dim3 grid(nblk);
     if (md <= 5)
       hipLaunchKernelGGL((sfc_wgrad_kernel<5>), grid, dim3(256), 0, st, A);
     else
@@ -1137,7 +1192,9 @@ int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, cons
   if (lds > SFC_LDS_LIMIT) return EQF_E_UNSUPPORTED;
   const int md = max_d1(A.c) > d3max ? max_d1(A.c) : d3max;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(eqf_cdiv(E, B_TE), A.ngrp);
+  int nblk = 0;
+  A.ord = make_order(1, eqf_cdiv(E, B_TE), A.ngrp, nblk);
+  dim3 grid(nblk);
   const int pid = eqf_prof_begin("sfc_bwd_data", st, sfc_flops(A.c), sfc_bytes(A.c));
   if (md <= 5) {
     static bool attr5 = false;

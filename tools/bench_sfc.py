@@ -14,6 +14,7 @@ from equiformer_amd.layout import DtpTable, RowLayout  # noqa: E402
 from equiformer_amd.lib import call  # noqa: E402
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 25354
+ORDERS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1]
 dev = torch.device("cuda:0")
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -77,10 +78,13 @@ def run(name, irr, sh_irr, out_irr, n2, use_w):
     nb = ((E + 31) // 32)
     print("%-10s bwd_data phase cycles per workgroup-row (sum over groups / edge tiles): prologue %.0f staging %.0f mfma %.0f "
           "epilogue %.0f store %.0f" % ((name,) + tuple(v / nb for v in d[:5])), flush=True)
-    for tag, fn in (("fwd", f), ("bwd_data", b), ("bwd_weight", wg)):
-        us = timeit(fn)
-        print("%-10s %-10s E=%d  %8.1f us  %6.1f TFLOP/s  (%.2f GFLOP)" % (name, tag, E, us, flops / us / 1e6, flops / 1e9),
-              flush=True)
+    for order in ORDERS:
+        _lib.load().eqf_sfc_debug_order(order)
+        for tag, fn in (("fwd", f), ("bwd_data", b), ("bwd_weight", wg)):
+            us = timeit(fn)
+            print("%-10s order %d %-10s E=%d  %8.1f us  %6.1f TFLOP/s  (%.2f GFLOP)"
+                  % (name, order, tag, E, us, flops / us / 1e6, flops / 1e9), flush=True)
+    _lib.load().eqf_sfc_debug_order(-1)
 
 
 run("sep_act", "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "224x0e+64x1e+32x2e", 128, True)
