@@ -37,6 +37,7 @@ unsigned long long* g_sfc_dbg = nullptr;  // set by eqf_sfc_debug_buffer (develo
 // 8-12 % faster for bwd_weight, 0-6 % for bwd_data, and 0-14 % SLOWER for fwd (its workgroups of one degree share the
 // staged weight slabs, which the degree-major order keeps hot).  eqf_sfc_debug_order overrides all three for A/B runs.
 int g_sfc_order[3] = {0, 1, 1};
+int g_sfc_exp = 0;  // development aid (eqf_sfc_debug_exp): bit mask that switches phases of the kernels OFF to time the rest
 
 constexpr int SFC_MAX_DEG = 4;
 constexpr int SFC_MAX_SLABS = 72;   // 32-channel slabs over all output degrees (DTP width <= 3072 channels)
@@ -132,6 +133,8 @@ struct SfcFwdArgs {
   const float* bias;   // [N1 of degree 0] or null
   const float* bias2;  // [N2] or null
   unsigned long long* dbg;  // optional phase timers (development aid), may be null
+  int grp_floats;           // LDS floats per 256-thread group (paired workgroups)
+  int exp;                  // development aid: 1 no MFMA, 2 no generation, 4 no loads after the first slab, 8 no weight loads
   int nsplit[SFC_MAX_DEG], cps[SFC_MAX_DEG];
   SfcOrder ord;                                // nx = edge tiles, ny = (degree, column split) pairs
   signed char y_deg[16], y_split[16];
@@ -171,23 +174,33 @@ __device__ __forceinline__ void f_mma(const int (&aidx)[FT], const int (&bidx)[F
   }
 }
 
-template <int D3, int MAXD>
+// PAIR: the workgroup has 512 threads = two independent 256-thread groups working on neighbouring edge tiles with
+// their own LDS partitions, run in ANTI-PHASE through the shared barriers: while one group's waves issue the MFMAs of
+// slab s, the other group's waves (the co-resident wave of every SIMD) wait for loads, generate the next A tile on the
+// VALU and write LDS.  Two free-running 256-thread workgroups per CU do the same work with the same resources, but
+// measured additively (MFMA 120 us + loads 45 + generation 30 + fixed 66 of 246 us: tools/sfc_exp.py): nothing forces
+// their matrix-pipe and memory phases apart.
+template <int D3, int MAXD, bool PAIR>
 __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const int b) {
   constexpr int ROWS = F_TE * D3, RT = ROWS / 32, SA = ROWS + 1;
   constexpr int FT = (MAXD <= 5) ? 3 : F_MAXT;  // accumulator tiles per wave (host: `ft`)
   constexpr int CTCAP = f_ctcap(D3, FT), F_SB = f_sb(D3, FT);
   const SfcDeg& D = g.c.deg[di];
   const int nsplit = g.nsplit[di];
-  const int tile = b / nsplit, ns = b - tile * nsplit;
-  const int e0 = tile * F_TE;
-  const int ecnt = min(F_TE, g.c.E - e0);
+  const int grp = PAIR ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+  const int xt = b / nsplit, ns = b - xt * nsplit;
+  const int tile = PAIR ? 2 * xt + grp : xt;
+  int e0 = tile * F_TE;
+  int ecnt = min(F_TE, g.c.E - e0);
+  if (ecnt <= 0) ecnt = 0, e0 = 0;  // odd tile count: the idle group runs along (barriers) on row 0 and stores nothing
   const int ncol0 = ns * g.cps[di];
   const int ncols = min(g.cps[di], D.Ncat - ncol0);
   const int CT = ncols >> 5;
-  constexpr int AS0 = 0, BS0 = 32 * SA, MT0 = BS0 + 32 * F_SB;  // LDS partition (float offsets into sfc_lds)
+  // LDS partition of this group (float offsets into sfc_lds)
+  const int AS0 = grp * g.grp_floats, BS0 = AS0 + 32 * SA, MT0 = BS0 + 32 * F_SB;
   const int m_len = D.m_len;
 
-  const int t = threadIdx.x;
+  const int t = PAIR ? ((int)threadIdx.x & 255) : (int)threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = t & 63, r = lane & 31, hi = lane >> 5;
 
@@ -209,12 +222,6 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     bidx[i] = BS0 + hi * F_SB + r + boff[i];
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-  }
-
-  // coupling tile: Mt[el][j] = coupling[e0+el, m_base + j]; rows of edges beyond the graph are zero
-  for (int i = t; i < F_TE * m_len; i += 256) {
-    const int el = i / m_len, j = i - el * m_len;
-    sfc_lds[MT0 + i] = (el < ecnt) ? g.c.coupling[(long)(e0 + el) * g.c.m_ld + D.m_base + j] : 0.f;
   }
 
   // Generation mapping: thread = (channel quad c4 = t & 7 -> channels 4 c4 .. 4 c4 + 3 of the slab, edges eg and eg + 32
@@ -265,6 +272,7 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     // column blocks beyond CT re-read the last valid block (their LDS columns are never used): no guards, no
     // dynamic indexing of bv
     const int wk = s * 32 + (t >> 3);  // row of the weight matrices
+    if (!(g.exp & 8))
 #pragma unroll
     for (int j = 0; j < CTCAP; ++j) {
       const int c = ncol0 + 32 * (j < CT ? j : CT - 1);  // 32-column block: entirely main or entirely second consumer
@@ -293,7 +301,7 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
   };
   const int bwp = BS0 + (t >> 3) * F_SB + 4 * (t & 7);
   auto commit = [&]() __attribute__((always_inline)) {
-    switch (s_d1) {
+    if (!(g.exp & 2)) switch (s_d1) {
       case 1: gen(IC<1>()); break;
       case 3: gen(IC<3>()); break;
       case 5: gen(IC<(MAXD >= 5 ? 5 : 1)>()); break;
@@ -312,17 +320,40 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     }
   };
   issue(0);
+  // coupling tile: Mt[el][j] = coupling[e0+el, m_base + j]; rows of edges beyond the graph are zero.  Loads are
+  // unconditional (clamped addresses) and batched: a one-element-per-iteration loop compiles to load / s_waitcnt
+  // vmcnt(0) / ds_write per element, i.e. a chain of ~28 full memory round trips per workgroup (measured: 27 % of
+  // the kernel).
+  {
+    const int total = F_TE * m_len;
+    constexpr int MU = 7;
+    const float* cp = g.c.coupling + D.m_base;
+    for (int i0 = t; i0 < total; i0 += 256 * MU) {
+      float v[MU];
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int i = min(i0 + 256 * u, total - 1);
+        const int el = i / m_len, j = i - el * m_len;
+        const float val = cp[(long)(e0 + (el < ecnt ? el : 0)) * g.c.m_ld + j];
+        v[u] = (el < ecnt) ? val : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < MU; ++u)
+        if (i0 + 256 * u < total) sfc_lds[MT0 + i0 + 256 * u] = v[u];
+    }
+  }
   __syncthreads();
   tick(0);  // prologue
+  if (PAIR && grp == 1) __syncthreads();  // half a slab step behind group 0 from here on
   const int nslab = D.nslab;
   for (int s = 0; s < nslab; ++s) {
     commit();
     tick(1);  // wait for the prefetched inputs + generation + LDS writes
     __syncthreads();
     tick(2);  // barrier
-    if (s + 1 < nslab) issue(s + 1);
+    if (s + 1 < nslab && !(g.exp & 4)) issue(s + 1);
     tick(3);  // issue of the next slab's loads
-    switch (NT) {
+    if (!(g.exp & 1)) switch (NT) {
       case 1: f_mma<D3, 1, FT>(aidx, bidx, acc); break;
       case 2: f_mma<D3, 2, FT>(aidx, bidx, acc); break;
       case 3: f_mma<D3, 3, FT>(aidx, bidx, acc); break;
@@ -360,20 +391,21 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
       if (el < ecnt) base[(long)(e0 + el) * ld + coff + m3 * mstride] = acc[i][q] + bvl;
     }
   }
+  if (PAIR && grp == 0) __syncthreads();  // the barrier that ends group 1's last MFMA phase
 }
 
-template <int MAXD>
-__global__ __launch_bounds__(256, (MAXD <= 5 ? 2 : 1)) void sfc_fwd_kernel(const SfcFwdArgs g) {
+template <int MAXD, bool PAIR>
+__global__ __launch_bounds__((PAIR ? 512 : 256), (PAIR || MAXD > 5 ? 1 : 2)) void sfc_fwd_kernel(const SfcFwdArgs g) {
   int tile, y;
   if (!order_xy(g.ord, blockIdx.x, tile, y)) return;
   const int di = g.y_deg[y];
   const int b = tile * g.nsplit[di] + g.y_split[y];
   switch (g.c.deg[di].d3) {
-    case 1: f_block<1, MAXD>(g, di, b); break;
-    case 3: f_block<3, MAXD>(g, di, b); break;
-    case 5: f_block<5, MAXD>(g, di, b); break;
+    case 1: f_block<1, MAXD, PAIR>(g, di, b); break;
+    case 3: f_block<3, MAXD, PAIR>(g, di, b); break;
+    case 5: f_block<5, MAXD, PAIR>(g, di, b); break;
     default:
-      if constexpr (MAXD >= 7) f_block<7, MAXD>(g, di, b);
+      if constexpr (MAXD >= 7) f_block<7, MAXD, PAIR>(g, di, b);
       break;
   }
 }
@@ -438,11 +470,29 @@ __device__ __forceinline__ void wg_wave(const SfcWgArgs& g, const SfcSlab& S, co
 #pragma unroll
       for (int ct = 0; ct < CTT; ++ct) bq[slot][m3][ct] = cb[ct][er * cld[ct] + r + m3 * cm3[ct]];
   };
+  // Coupling matrices of W_SUB edges at a time in this wave's LDS block: the loads of a lane are issued in batches of
+  // NB before the LDS writes.  The first version loaded one edge per iteration -- load / s_waitcnt vmcnt(0) /
+  // ds_write, 32 memory round trips in a row for every 32 edges, more than the MFMA time of those edges.  (Fetching
+  // the next block a whole block ahead costs 13 live registers and made hipcc spill.)
+  constexpr int NL = (W_SUB * LEN + 63) / 64;
+  constexpr int NB = NL < 5 ? NL : 5;  // loads in flight per lane (register budget)
+  const float* cpl = g.c.coupling + S.m_off;
+  const unsigned m_ld = g.c.m_ld;
   auto stage_m = [&](int s0) __attribute__((always_inline)) {
     __builtin_amdgcn_wave_barrier();
-    for (int el = 0; el < W_SUB; ++el) {
-      const int e = s0 + el;
-      if (e < eend && lane < LEN) Mw[el * LEN + lane] = g.c.coupling[(long)e * g.c.m_ld + S.m_off + lane];
+#pragma unroll
+    for (int k0 = 0; k0 < NL; k0 += NB) {
+      float mreg[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int idx = min(lane + 64 * (k0 + k), W_SUB * LEN - 1);
+        const int el = idx / LEN, j = idx - el * LEN;
+        const int e = min(s0 + el, eend - 1);  // rows past the range: a finite copy of the last valid row (their w is 0)
+        mreg[k] = cpl[(unsigned)e * m_ld + (unsigned)j];
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+        if (k0 + k < NL && lane + 64 * (k0 + k) < W_SUB * LEN) Mw[lane + 64 * (k0 + k)] = mreg[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -598,6 +648,7 @@ struct SfcBwdArgs {
   int dt_floats;  // LDS partition
   int full_m;     // the LDS coupling block holds whole coupling rows (mt_len == m_ld, mt_off == m_off)
   SfcOrder ord;   // nx = edge tiles, ny = chunk groups
+  int exp;        // development aid: 1 no MFMA loop, 2 no register epilogue, 4 no d_out staging after the first
   unsigned long long* dbg;  // optional phase timers (cycles of wave 0 / lane 0 of every workgroup), may be null
   SfcBGroup grp[B_MAXGRP];
 };
@@ -648,16 +699,47 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
       }
   // coupling matrices: either the whole (contiguous) coupling rows of the 32 edges in one coalesced pass, or -- when
   // those do not fit (L_max = 3) -- only the matrices of the group's paths
+  // (batched, unconditional loads with clamped addresses -- see the forward kernel)
   if (g.full_m) {
     const float* src = g.c.coupling + (long)e0 * g.c.m_ld;
-    for (int i = t; i < B_TE * mt_len; i += 256) Mt[i] = (i < ecnt * mt_len) ? src[i] : 0.f;
+    const int total = B_TE * mt_len, nvalid = ecnt * mt_len;
+    constexpr int MU = 9;
+    for (int i0 = t; i0 < total; i0 += 256 * MU) {
+      float v[MU];
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int i = i0 + 256 * u;
+        const float val = src[min(i, nvalid - 1)];
+        v[u] = (i < nvalid) ? val : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < MU; ++u)
+        if (i0 + 256 * u < total) Mt[i0 + 256 * u] = v[u];
+    }
   } else {
     for (int pi = 0; pi < G.npath; ++pi) {
       const SfcBPath P = G.p[pi];
       const int len = D1 * g.c.deg[P.deg].d3;
-      for (int i = t; i < B_TE * len; i += 256) {
-        const int el = i / len, jj = i - el * len;
-        Mt[el * mt_len + P.mt_off + jj] = (el < ecnt) ? g.c.coupling[(long)(e0 + el) * g.c.m_ld + P.m_off + jj] : 0.f;
+      const int total = B_TE * len;
+      constexpr int MU = 7;
+      const float* cp = g.c.coupling + P.m_off;
+      for (int i0 = t; i0 < total; i0 += 256 * MU) {
+        float v[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+          const int i = min(i0 + 256 * u, total - 1);
+          const int el = i / len, jj = i - el * len;
+          const float val = cp[(long)(e0 + (el < ecnt ? el : 0)) * g.c.m_ld + jj];
+          v[u] = (el < ecnt) ? val : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+          const int i = i0 + 256 * u;
+          if (i < total) {
+            const int el = i / len, jj = i - el * len;
+            Mt[el * mt_len + P.mt_off + jj] = v[u];
+          }
+        }
       }
     }
   }
@@ -703,7 +785,7 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
         // fragments of the first two k blocks (segment lengths are multiples of 32): in flight across the staging
         f32x4 bA = *reinterpret_cast<const f32x4*>(rowA + kc0);
         f32x4 bB = *reinterpret_cast<const f32x4*>(rowA + kc0 + 16);
-        if (!(nchunk == 1 && staged_deg == P.deg)) {
+        if (!(nchunk == 1 && staged_deg == P.deg) && !((g.exp & 4) && staged_deg >= 0)) {
           __syncthreads();  // readers of the previous Dt contents are done
           // stage Dt[k][row] = d_out[e0 + el, m3, kc0 + k],  row = m3*32 + el.  A wave step covers 16 float4 columns x
           // 4 rows; all loads of a group of column blocks are issued before the first LDS write.
@@ -793,8 +875,8 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
           }
           if (kb < kb1) pair(bA, bB, kb);  // segment lengths are multiples of 32: at most one pair is left
         };
-        seg(0, endA, rowA);
-        if (endA < kcn) {
+        if (!(g.exp & 1)) seg(0, endA, rowA);
+        if (endA < kcn && !(g.exp & 1)) {
           bA = *reinterpret_cast<const f32x4*>(w2row + kc0 + endA);
           bB = *reinterpret_cast<const f32x4*>(w2row + kc0 + endA + 16);
           seg(endA, kcn, w2row);
@@ -802,6 +884,7 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
       }
       tick(2);  // MFMA loop
       // DTP backward contraction in registers: this lane holds d_mid[m3][edge el0+q][channel 32c + ch]
+      if (!(g.exp & 2))
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float gw = 0.f;
@@ -979,6 +1062,11 @@ int eqf_sfc_debug_order(int mode) {
   return 0;
 }
 
+int eqf_sfc_debug_exp(int mask) {
+  g_sfc_exp = mask;
+  return 0;
+}
+
 int eqf_sfc_debug_buffer(void* p) {
   g_sfc_dbg = (unsigned long long*)p;
   return 0;
@@ -995,6 +1083,7 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
   A.bias = bias0;
   A.bias2 = bias2;
   A.dbg = g_sfc_dbg;
+  A.exp = g_sfc_exp;
   int md = max_d1(A.c);
   for (int d = 0; d < A.c.ndeg; ++d) md = A.c.deg[d].d3 > md ? A.c.deg[d].d3 : md;
   const int ft = md <= 5 ? 3 : F_MAXT;
@@ -1020,26 +1109,26 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
     if (need > lds) lds = need;
   }
   if (lds > SFC_LDS_LIMIT) return EQF_E_UNSUPPORTED;
+  lds = (lds + 15) & ~(size_t)15;
+  // paired workgroups measured SLOWER than free-running ones (sep_act 297 vs 230 us, tools/sfc_exp.py): kept behind the
+  // development switch only
+  const bool pair = md <= 5 && 2 * lds <= SFC_LDS_LIMIT && (g_sfc_exp & 16);
+  A.grp_floats = (int)(lds / sizeof(float));
   int blk = 0;
-  A.ord = make_order(0, ntile, ny, blk);
+  A.ord = make_order(0, pair ? eqf_cdiv(ntile, 2) : ntile, ny, blk);
 
   hipStream_t st = (hipStream_t)stream;
   const int pid = eqf_prof_begin("sfc_fwd", st, sfc_flops(A.c), sfc_bytes(A.c));
-  if (md <= 5) {
-    static bool attr5 = false;
-    if (!attr5) {
-      hipFuncSetAttribute((const void*)sfc_fwd_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
-      attr5 = true;
-    }
-    hipLaunchKernelGGL(sfc_fwd_kernel<5>, dim3(blk), dim3(256), lds, st, A);
-  } else {
-    static bool attr7 = false;
-    if (!attr7) {
-      hipFuncSetAttribute((const void*)sfc_fwd_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
-      attr7 = true;
-    }
-    hipLaunchKernelGGL(sfc_fwd_kernel<7>, dim3(blk), dim3(256), lds, st, A);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)sfc_fwd_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
+    hipFuncSetAttribute((const void*)sfc_fwd_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
+    hipFuncSetAttribute((const void*)sfc_fwd_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
+    attr_set = true;
   }
+  if (pair) hipLaunchKernelGGL((sfc_fwd_kernel<5, true>), dim3(blk), dim3(512), 2 * lds, st, A);
+  else if (md <= 5) hipLaunchKernelGGL((sfc_fwd_kernel<5, false>), dim3(blk), dim3(256), lds, st, A);
+  else hipLaunchKernelGGL((sfc_fwd_kernel<7, false>), dim3(blk), dim3(256), lds, st, A);
   eqf_prof_end(pid, st);
   EQF_CHECK_LAUNCH();
   return 0;
@@ -1122,6 +1211,7 @@ int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, cons
   if (E <= 0) return 0;
   A.dx = dx, A.dw = (w ? dw : nullptr), A.dM = d_coupling;
   A.dbg = g_sfc_dbg;
+  A.exp = g_sfc_exp;
   // groups = (input segment, 32-channel chunk); paths sorted by output degree so that a staged d_out tile is shared
   A.ngrp = 0;
   int d3max = 1, mtmax = 0;
