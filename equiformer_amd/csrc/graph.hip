@@ -42,6 +42,106 @@ __global__ __launch_bounds__(64) void radius_fill_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------- CSR bookkeeping
+// ptr[g] = first i with seg_of[i] >= g (seg_of ascending), ptr[n_seg] = n; optional max segment length.
+__global__ __launch_bounds__(256) void segment_ptr_kernel(const int* __restrict__ seg_of, int n, int n_seg,
+                                                          int* __restrict__ ptr, int* __restrict__ max_len) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > n_seg) return;
+  auto lower = [&](int key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (seg_of[mid] < key) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  };
+  const int a = lower(g);
+  ptr[g] = a;
+  if (max_len && g < n_seg) atomicMax(max_len, lower(g + 1) - a);
+}
+
+// ptr[0..n] = exclusive scan of counts[0..n-1]; one workgroup (n is a node count), serial chunks + one LDS scan.
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int* __restrict__ counts, int n, int* __restrict__ ptr,
+                                                              int* __restrict__ total) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int i0 = min(n, t * chunk), i1 = min(n, i0 + chunk);
+  int s = 0;
+  for (int i = i0; i < i1; ++i) s += counts[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int i = i0; i < i1; ++i) {
+    ptr[i] = run;
+    run += counts[i];
+  }
+  if (t == 1023) {
+    ptr[n] = part[1023];
+    if (total) *total = part[1023];
+  }
+}
+
+// By-source view of a dst-sorted, molecule-blocked edge list: src_perm = stable argsort of src, src_ptr = CSR offsets
+// over the source node.  Edges never cross molecules, so the by-source order is molecule-blocked too and occupies the
+// same edge range: one workgroup per molecule, counters in LDS.  Inside one destination row every source occurs at
+// most once (radius graphs have no multi-edges), so walking the rows in order and bumping a per-source cursor
+// reproduces the stable order without any sort.
+constexpr int CSR_MAX_NODES = 16384;  // nodes per molecule (64 KB of LDS cursors)
+__global__ __launch_bounds__(256) void csr_by_source_kernel(const int* __restrict__ src, const int* __restrict__ row_ptr,
+                                                            const int* __restrict__ mol_ptr, int n_mol,
+                                                            int* __restrict__ src_perm, int* __restrict__ src_ptr) {
+  extern __shared__ int cur[];  // [nm]
+  __shared__ int part[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int n0 = mol_ptr[b], n1 = mol_ptr[b + 1], nm = n1 - n0;
+  const int e0 = row_ptr[n0], e1 = row_ptr[n1];
+  for (int i = t; i < nm; i += 256) cur[i] = 0;
+  __syncthreads();
+  for (int e = e0 + t; e < e1; e += 256) atomicAdd(&cur[src[e] - n0], 1);
+  __syncthreads();
+  // exclusive scan of cur[0..nm) in place
+  const int chunk = (nm + 255) / 256;
+  const int i0 = min(nm, t * chunk), i1 = min(nm, i0 + chunk);
+  int s = 0;
+  for (int i = i0; i < i1; ++i) s += cur[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = e0 + part[t] - s;
+  for (int i = i0; i < i1; ++i) {
+    const int c = cur[i];
+    cur[i] = run;
+    src_ptr[n0 + i] = run;
+    run += c;
+  }
+  if (b == n_mol - 1 && t == 0) src_ptr[n1] = e1;
+  __syncthreads();
+  for (int d = n0; d < n1; ++d) {
+    const int r0 = row_ptr[d], r1 = row_ptr[d + 1];
+    for (int e = r0 + t; e < r1; e += 256) {
+      const int sn = src[e] - n0;
+      const int pos = cur[sn];
+      cur[sn] = pos + 1;
+      src_perm[pos] = e;
+    }
+    __syncthreads();
+  }
+}
+
 // raw (norm-normalised) real spherical harmonics l = 2 and their gradients wrt the unit vector
 struct SH2 {
   float v[5];
@@ -306,6 +406,43 @@ int eqf_radius_graph_fill(const float* pos, const int* mol_ptr, int n_mol, float
   if (n_mol <= 0) return 0;
   hipLaunchKernelGGL(radius_fill_kernel, dim3(n_mol), dim3(64), 0, (hipStream_t)stream, pos, mol_ptr, r * r, max_nbr,
                      row_ptr, src, dst);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_segment_ptr(const int* seg_of, int n, int n_seg, int* ptr, int* max_len, void* stream) {
+  if (!ptr || (n > 0 && !seg_of) || n < 0 || n_seg < 0) return EQF_E_BADARG;
+  if (max_len) {
+    hipError_t e = hipMemsetAsync(max_len, 0, sizeof(int), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(segment_ptr_kernel, dim3(eqf_cdiv(n_seg + 1, 256)), dim3(256), 0, (hipStream_t)stream, seg_of, n,
+                     n_seg, ptr, max_len);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_exclusive_scan_i32(const int* counts, int n, int* ptr, int* total, void* stream) {
+  if (!ptr || (n > 0 && !counts) || n < 0) return EQF_E_BADARG;
+  hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n, ptr, total);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_csr_by_source(const int* src, const int* row_ptr, const int* mol_ptr, int n_mol, int max_mol_nodes,
+                      int* src_perm, int* src_ptr, void* stream) {
+  if (!row_ptr || !mol_ptr || !src_perm || !src_ptr || !src) return EQF_E_BADARG;
+  if (max_mol_nodes > CSR_MAX_NODES) return EQF_E_UNSUPPORTED;
+  if (n_mol <= 0) return 0;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)csr_by_source_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        CSR_MAX_NODES * (int)sizeof(int));
+    attr = true;
+  }
+  const size_t lds = sizeof(int) * (size_t)(max_mol_nodes > 0 ? max_mol_nodes : 1);
+  hipLaunchKernelGGL(csr_by_source_kernel, dim3(n_mol), dim3(256), lds, (hipStream_t)stream, src, row_ptr, mol_ptr, n_mol,
+                     src_perm, src_ptr);
   EQF_CHECK_LAUNCH();
   return 0;
 }

@@ -1127,7 +1127,8 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
     attr_set = true;
   }
   if (pair) hipLaunchKernelGGL((sfc_fwd_kernel<5, true>), dim3(blk), dim3(512), 2 * lds, st, A);
-  else if (md <= 5) hipLaunchKernelGGL((sfc_fwd_kernel<5, false>), dim3(blk), dim3(256), lds, st, A);
+  else if (md <= 5)
+    hipLaunchKernelGGL((sfc_fwd_kernel<5, false>), dim3(blk), dim3(256), (g_sfc_exp & 32) ? (size_t)100 * 1024 : lds, st, A);
   else hipLaunchKernelGGL((sfc_fwd_kernel<7, false>), dim3(blk), dim3(256), lds, st, A);
   eqf_prof_end(pid, st);
   EQF_CHECK_LAUNCH();
@@ -1292,7 +1293,7 @@ int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, cons
       hipFuncSetAttribute((const void*)sfc_bwd_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
       attr5 = true;
     }
-    hipLaunchKernelGGL(sfc_bwd_kernel<5>, grid, dim3(256), lds, st, A);
+    hipLaunchKernelGGL(sfc_bwd_kernel<5>, grid, dim3(256), (g_sfc_exp & 32) ? (size_t)100 * 1024 : lds, st, A);
   } else {
     static bool attr7 = false;
     if (!attr7) {

@@ -22,17 +22,36 @@ def _ptr_from_counts(counts):
     return _i32(torch.cat([z, torch.cumsum(counts.to(torch.int64), 0)]))
 
 
+def _P(t, byte_offset=0):
+    return ctypes.c_void_p(t.data_ptr() + byte_offset) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+CSR_MAX_NODES = 16384  # nodes per molecule the by-source kernel keeps cursors for (csrc/graph.hip)
+
+
 class EdgeGraph:
     """N nodes, E directed edges sorted by dst.  All index tensors are int32 on the GPU."""
 
-    def __init__(self, N, src, dst, row_ptr, batch=None, num_graphs=None):
+    def __init__(self, N, src, dst, row_ptr, batch=None, num_graphs=None, mol_ptr=None, max_mol_nodes=None):
         self.N = int(N)
         self.src, self.dst, self.row_ptr = src, dst, row_ptr
         self.E = int(src.shape[0])
         # by-source view: edges grouped by src (for gradients that flow back to the source node)
-        order = torch.argsort(src.to(torch.int64), stable=True)
-        self.src_perm = _i32(order)
-        self.src_ptr = _ptr_from_counts(torch.bincount(src.to(torch.int64), minlength=self.N))
+        if mol_ptr is not None and max_mol_nodes is not None and max_mol_nodes <= CSR_MAX_NODES and src.is_cuda:
+            # radius graphs: molecule-blocked, no multi-edges -> one HIP launch instead of a device sort
+            self.src_perm = torch.empty(self.E, dtype=torch.int32, device=src.device)
+            self.src_ptr = torch.empty(self.N + 1, dtype=torch.int32, device=src.device)
+            call("eqf_csr_by_source", _P(src), _P(row_ptr), _P(mol_ptr), int(mol_ptr.shape[0]) - 1, int(max_mol_nodes),
+                 _P(self.src_perm), _P(self.src_ptr), _stream())
+        else:
+            # arbitrary edge lists (periodic images can repeat a source inside a row): stable device sort
+            order = torch.argsort(src.to(torch.int64), stable=True)
+            self.src_perm = _i32(order)
+            self.src_ptr = _ptr_from_counts(torch.bincount(src.to(torch.int64), minlength=self.N))
         self.batch = None
         if batch is not None:
             self.set_batch(batch, num_graphs)
@@ -53,19 +72,23 @@ class EdgeGraph:
         N = pos.shape[0]
         if num_graphs is None:
             num_graphs = int(batch[-1].item()) + 1
-        mol_ptr = _ptr_from_counts(torch.bincount(batch.to(torch.int64), minlength=num_graphs))
-        deg = torch.empty(N, dtype=torch.int32, device=pos.device)
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        P = lambda t: ctypes.c_void_p(t.data_ptr())
-        call("eqf_radius_graph_count", P(pos), P(mol_ptr), num_graphs, float(r), int(max_num_neighbors), P(deg), st)
-        row_ptr = _ptr_from_counts(deg)
-        E = int(row_ptr[-1].item())  # the one host sync of graph construction (the reference syncs here as well)
-        src = torch.empty(E, dtype=torch.int32, device=pos.device)
-        dst = torch.empty(E, dtype=torch.int32, device=pos.device)
-        call("eqf_radius_graph_fill", P(pos), P(mol_ptr), num_graphs, float(r), int(max_num_neighbors), P(row_ptr),
-             P(src), P(dst), st)
-        g = EdgeGraph(N, src, dst, row_ptr)
-        g.batch = _i32(batch)
+        dev = pos.device
+        b32 = _i32(batch)
+        st = _stream()
+        stats = torch.empty(2, dtype=torch.int32, device=dev)  # [E, nodes of the largest molecule]
+        mol_ptr = torch.empty(num_graphs + 1, dtype=torch.int32, device=dev)
+        call("eqf_segment_ptr", _P(b32), N, int(num_graphs), _P(mol_ptr), _P(stats, 4), st)
+        deg = torch.empty(N, dtype=torch.int32, device=dev)
+        call("eqf_radius_graph_count", _P(pos), _P(mol_ptr), num_graphs, float(r), int(max_num_neighbors), _P(deg), st)
+        row_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        call("eqf_exclusive_scan_i32", _P(deg), N, _P(row_ptr), _P(stats), st)
+        E, max_mol_nodes = stats.tolist()  # the one host sync of graph construction (the reference syncs here as well)
+        src = torch.empty(E, dtype=torch.int32, device=dev)
+        dst = torch.empty(E, dtype=torch.int32, device=dev)
+        call("eqf_radius_graph_fill", _P(pos), _P(mol_ptr), num_graphs, float(r), int(max_num_neighbors), _P(row_ptr),
+             _P(src), _P(dst), st)
+        g = EdgeGraph(N, src, dst, row_ptr, mol_ptr=mol_ptr, max_mol_nodes=max_mol_nodes)
+        g.batch = b32
         g.num_graphs = int(num_graphs)
         g.mol_ptr = mol_ptr
         return g

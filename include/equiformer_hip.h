@@ -80,6 +80,20 @@ int eqf_radius_graph_count(const float* pos, const int* mol_ptr, int n_mol, floa
 int eqf_radius_graph_fill(const float* pos, const int* mol_ptr, int n_mol, float r, int max_nbr,
                           const int* row_ptr, int* src, int* dst, void* stream);
 
+/* CSR bookkeeping of the graph (replaces torch.bincount / cumsum / argsort around the radius graph; the reference
+ * gets the same quantities from torch_cluster / torch_scatter internals and `degree`,
+ * nets/graph_attention_transformer.py:866-867,517).
+ * eqf_segment_ptr: seg_of[n] ascending (PyG `batch`) -> ptr[n_seg+1] with ptr[g] = first i with seg_of[i] >= g;
+ *   max_len (may be NULL) receives the longest segment.
+ * eqf_exclusive_scan_i32: ptr[0..n] = exclusive prefix sums of counts[n]; total (may be NULL) receives ptr[n].
+ * eqf_csr_by_source: for a dst-sorted edge list whose edges never cross the molecules of mol_ptr and whose rows
+ *   hold every source at most once: src_perm[E] = stable argsort of src, src_ptr[N+1] = offsets of the by-source
+ *   groups.  max_mol_nodes = an upper bound of the nodes per molecule (<= 16384, else EQF_E_UNSUPPORTED).          */
+int eqf_segment_ptr(const int* seg_of, int n, int n_seg, int* ptr, int* max_len, void* stream);
+int eqf_exclusive_scan_i32(const int* counts, int n, int* ptr, int* total, void* stream);
+int eqf_csr_by_source(const int* src, const int* row_ptr, const int* mol_ptr, int n_mol, int max_mol_nodes,
+                      int* src_perm, int* src_ptr, void* stream);
+
 /* edge_vec = pos[src] - pos[dst] (+ offsets, may be NULL), len = |edge_vec|,
  * sh = Y^0..Y^lmax(edge_vec/len) * sqrt(2l+1)  ("component" normalisation), lmax <= 3.
  * [ref: nets/graph_attention_transformer.py:868-870,874;  e3nn o3.spherical_harmonics] */

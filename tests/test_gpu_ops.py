@@ -233,6 +233,35 @@ def test_radius_graph_matches_oracle():
     g2 = EdgeGraph.from_radius(d["pos"].to(dev), d["batch"].to(dev), 5.0, max_num_neighbors=4)
     s2, d2 = onets.radius_graph(d["pos"], 5.0, d["batch"], max_num_neighbors=4)
     assert torch.equal(g2.src.cpu().long(), s2) and torch.equal(g2.dst.cpu().long(), d2)
+    # CSR bookkeeping kernels (segment offsets, exclusive scan, by-source permutation) are bit-exact against the
+    # stable sort / bincount they replace -- also on the truncated (asymmetric) graph and on ragged molecule sizes
+    for gg, ss in ((g, src), (g2, s2)):
+        assert torch.equal(gg.src_perm.cpu().long(), torch.argsort(ss, stable=True))
+        cnt = torch.bincount(ss, minlength=gg.N)
+        assert torch.equal(gg.src_ptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]))
+        assert torch.equal(gg.mol_ptr.cpu().long(), torch.arange(0, 7 * 18 + 1, 18))
+
+
+def test_csr_bookkeeping_ragged():
+    from equiformer_amd.graph import EdgeGraph
+    dev = _dev()
+    g0 = torch.Generator().manual_seed(5)
+    sizes = [1, 7, 300, 2, 33, 1, 64]  # single-atom molecules have no edges; one molecule larger than a workgroup
+    batch = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes)])
+    pos = torch.cat([torch.rand(n, 3, generator=g0) * (2.0 + n ** (1 / 3.0) * 1.5) for n in sizes])
+    g = EdgeGraph.from_radius(pos.to(dev), batch.to(dev), 3.0)
+    src, dst = onets.radius_graph(pos, 3.0, batch)
+    assert g.E == src.numel() and g.E > 0
+    assert torch.equal(g.src.cpu().long(), src) and torch.equal(g.dst.cpu().long(), dst)
+    assert torch.equal(g.src_perm.cpu().long(), torch.argsort(src, stable=True))
+    N = sum(sizes)
+    z = torch.zeros(1, dtype=torch.long)
+    assert torch.equal(g.src_ptr.cpu().long(), torch.cat([z, torch.bincount(src, minlength=N).cumsum(0)]))
+    assert torch.equal(g.row_ptr.cpu().long(), torch.cat([z, torch.bincount(dst, minlength=N).cumsum(0)]))
+    assert torch.equal(g.mol_ptr.cpu().long(), torch.cat([z, torch.tensor(sizes).cumsum(0)]))
+    # empty trailing molecule ids (num_graphs larger than the last id + 1)
+    g3 = EdgeGraph.from_radius(pos.to(dev), batch.to(dev), 3.0, num_graphs=len(sizes) + 2)
+    assert torch.equal(g3.src_perm.cpu(), g.src_perm.cpu()) and g3.mol_ptr.cpu().tolist()[-3:] == [N, N, N]
 
 
 @pytest.mark.parametrize("lmax", [1, 2, 3])

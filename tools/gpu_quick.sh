@@ -1,4 +1,3 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2i; export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "sfc or separable" 2>&1 | tail -3
-timeout 300 python tools/sfc_exp.py 2>&1 | grep exp | tee gpurun_out/r2i/sfc_exp2.txt
-timeout 300 python tools/bench_sfc.py 25354 2>&1 | grep order | tee gpurun_out/r2i/sfc_bench2.txt
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2k; export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "radius or csr or geometry" 2>&1 | tail -12
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-260
