@@ -208,6 +208,30 @@ def main():
                 {"kernel": n2, "launches": r2["launches"], "avg_launch_ms": r2["total_ms"] / r2["launches"],
                  "achieved": r2["flops"] / r2["total_ms"] / 1e9, "share_of_step": r2["total_ms"] / (1e3 * dt)}
                 for n2, r2 in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]) if n2 != name][:6]
+        # the two kernels BASELINE.json's north_star asks to be stated against the gfx950 peaks (not part of the contract
+        # line): HBM GB/s of the per-destination softmax + scatter (algorithmic bytes 1 940 E + 1 920 N per call,
+        # SURVEY 8d) and MFMA rate of the radial MLP's widest layer (E x 64 -> 960)
+        extra = {}
+        sc = prof.get("attn_fwd")
+        if sc:
+            byts = 1940.0 * n_edges + 1920.0 * n_nodes
+            gbps = byts * sc["launches"] / sc["total_ms"] / 1e6
+            extra["scatter"] = {"kernel": "attn_fwd (segment softmax + aggregation)", "bound": "hbm", "achieved": gbps,
+                                "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                                "avg_launch_ms": sc["total_ms"] / sc["launches"], "algorithmic_bytes_per_launch": byts}
+        rad = [(n2, r2) for n2, r2 in prof.items() if n2.startswith("gemm_rows_128x128_mem")]
+        if rad:
+            n2, r2 = max(rad, key=lambda kv: kv[1]["total_ms"])
+            tf = r2["flops"] / r2["total_ms"] / 1e9
+            extra["radial_mlp"] = {"kernel": n2 + " (radial MLP 64 -> 960)", "bound": "mfma", "achieved": tf,
+                                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+                                   "avg_launch_ms": r2["total_ms"] / r2["launches"]}
+        # whole step against the HBM roofline of SURVEY 8d: 3.0 MB algorithmic bytes per molecule-step at E = 200
+        b_alg = 6 * (172800.0 + 1112.0 * n_edges / args.batch) + 0.29e6 + 0.33e6
+        extra["step_hbm_roofline"] = {"algorithmic_bytes_per_molecule": b_alg,
+                                      "molecules_per_s_at_peak": PEAK_HBM_GBPS * 1e9 / b_alg * world,
+                                      "frac": out["value"] / (PEAK_HBM_GBPS * 1e9 / b_alg * world)}
+        out["north_star_kernels"] = extra
         print("[bench] gpu part done: %.1f molecules/s, %.2f ms/step" % (out["value"], out["ms_per_step"]),
               file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:

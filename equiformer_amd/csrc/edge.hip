@@ -5,6 +5,7 @@
 // row, reads its incoming edge rows coalesced (1920-byte rows for 480 channels) and writes the node row
 // once -- no atomics, deterministic.  The softmax over incoming edges is reduced with wavefront shuffles.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -498,8 +499,12 @@ int eqf_attn_aggregate_fwd(const float* logit, const float* value, const int* ro
   const HeadTab T = make_headtab(*irreps, H, &err);
   if (err) return err;
   if (N <= 0) return 0;
+  // HBM-bound kernel: timed for the "HBM GB/s on the scatter" figure of bench.py (bytes are filled in there, the edge
+  // count lives on the device)
+  const int pid = eqf_prof_begin("attn_fwd", (hipStream_t)stream, 0.0, 0.0);
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, logit, value, row_ptr, alpha, out,
                      T, drop_p, seed);
+  eqf_prof_end(pid, (hipStream_t)stream);
   EQF_CHECK_LAUNCH();
   return 0;
 }
@@ -512,8 +517,10 @@ int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* ro
   const HeadTab T = make_headtab(*irreps, H, &err);
   if (err) return err;
   if (N <= 0) return 0;
+  const int pid = eqf_prof_begin("attn_bwd", (hipStream_t)stream, 0.0, 0.0);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, alpha, value, row_ptr, d_out,
                      d_value, d_logit, T, drop_p, seed);
+  eqf_prof_end(pid, (hipStream_t)stream);
   EQF_CHECK_LAUNCH();
   return 0;
 }
