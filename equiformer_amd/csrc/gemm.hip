@@ -510,7 +510,7 @@ int launch_rows(RowsArgs& a, hipStream_t st) {
   // 64-row tiles when 128-row tiles would leave most of the 256 CUs without a workgroup
   const int d = AMODE == A_DTP ? a.dtp.d3 : 1;
   const long tiles128 = (long)eqf_cdiv(a.M, (128 / d) * d) * eqf_cdiv(a.N, bn);
-  int bm = (bn >= 64 && tiles128 < 1024) ? 64 : 128;
+  int bm = (bn >= 64 && tiles128 < 4096) ? 64 : 128;
   if (AMODE == A_DTP) {
     if (bn >= 64 && ((128 / d) > 8 * ROWS_PAIRS || (128 / d) * a.dtp.m_len > MAX_MTILE)) bm = 64;
     a.dtp.ept = bm / d;
