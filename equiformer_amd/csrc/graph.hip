@@ -42,6 +42,111 @@ __global__ __launch_bounds__(64) void radius_fill_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------- periodic radius graph
+// ocpmodels.common.utils.radius_graph_pbc semantics (un-vendored dependency of the reference; restated in
+// oracle/pbc.py): candidates = (centre i, neighbour j of the same structure incl. j == i, image n with |n_k| <= rep_k),
+// kept when 1e-4 < |pos_j + n.cell - pos_i|^2 <= r^2; per centre the max_nbr nearest survive (ties: candidate order).
+struct PbcCell {
+  float a[3][3];
+  int rep[3];
+};
+__device__ __forceinline__ PbcCell pbc_cell(const float* __restrict__ cell, float r) {
+  PbcCell c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c.a[i][k] = cell[3 * i + k];
+  const double a1[3] = {c.a[0][0], c.a[0][1], c.a[0][2]}, a2[3] = {c.a[1][0], c.a[1][1], c.a[1][2]},
+               a3[3] = {c.a[2][0], c.a[2][1], c.a[2][2]};
+  auto cross = [](const double* u, const double* v, double* o) {
+    o[0] = u[1] * v[2] - u[2] * v[1], o[1] = u[2] * v[0] - u[0] * v[2], o[2] = u[0] * v[1] - u[1] * v[0];
+  };
+  double c23[3], c31[3], c12[3];
+  cross(a2, a3, c23), cross(a3, a1, c31), cross(a1, a2, c12);
+  const double vol = fabs(a1[0] * c23[0] + a1[1] * c23[1] + a1[2] * c23[2]);
+  const double* cs[3] = {c23, c31, c12};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double n = sqrt(cs[k][0] * cs[k][0] + cs[k][1] * cs[k][1] + cs[k][2] * cs[k][2]) / vol;
+    c.rep[k] = (int)ceil((double)r * n - 1e-12);
+  }
+  return c;
+}
+
+// visit the candidates of centre i in (j, n1, n2, n3) order: f(j, n1, n2, n3, d2, ox, oy, oz)
+template <class F>
+__device__ __forceinline__ void pbc_visit(const float* __restrict__ pos, const PbcCell& c, int n0, int n1_, int i, float r2,
+                                          F&& f) {
+  const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  for (int j = n0; j < n1_; ++j) {
+    const float dx0 = pos[3 * j] - xi, dy0 = pos[3 * j + 1] - yi, dz0 = pos[3 * j + 2] - zi;
+    for (int u = -c.rep[0]; u <= c.rep[0]; ++u)
+      for (int v = -c.rep[1]; v <= c.rep[1]; ++v)
+        for (int w = -c.rep[2]; w <= c.rep[2]; ++w) {
+          const float ox = u * c.a[0][0] + v * c.a[1][0] + w * c.a[2][0];
+          const float oy = u * c.a[0][1] + v * c.a[1][1] + w * c.a[2][1];
+          const float oz = u * c.a[0][2] + v * c.a[1][2] + w * c.a[2][2];
+          const float dx = dx0 + ox, dy = dy0 + oy, dz = dz0 + oz;
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          if (d2 <= r2 && d2 > 1e-4f) f(j, u, v, w, d2, ox, oy, oz);
+        }
+  }
+}
+
+__global__ __launch_bounds__(64) void pbc_count_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
+                                                       const int* __restrict__ mol_ptr, float r, int max_nbr,
+                                                       int* __restrict__ cand, int* __restrict__ deg) {
+  const int b = blockIdx.x;
+  const int n0 = mol_ptr[b], n1 = mol_ptr[b + 1];
+  const PbcCell c = pbc_cell(cell + 9 * b, r);
+  for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
+    int n = 0;
+    pbc_visit(pos, c, n0, n1, i, r * r, [&](int, int, int, int, float, float, float, float) { ++n; });
+    cand[i] = n;
+    deg[i] = n < max_nbr ? n : max_nbr;
+  }
+}
+
+__global__ __launch_bounds__(64) void pbc_fill_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
+                                                      const int* __restrict__ mol_ptr, float r, int max_nbr,
+                                                      const int* __restrict__ row_ptr, const int* __restrict__ cand_ptr,
+                                                      float* __restrict__ scratch_d2, int* __restrict__ src,
+                                                      int* __restrict__ dst, int* __restrict__ cell_offsets,
+                                                      float* __restrict__ offsets) {
+  const int b = blockIdx.x;
+  const int n0 = mol_ptr[b], n1 = mol_ptr[b + 1];
+  const PbcCell c = pbc_cell(cell + 9 * b, r);
+  for (int i = n0 + threadIdx.x; i < n1; i += blockDim.x) {
+    const int base = row_ptr[i], cnt = row_ptr[i + 1] - base;
+    const int cb = cand_ptr[i], ncand = cand_ptr[i + 1] - cb;
+    const bool trunc = ncand > cnt;
+    if (trunc) {  // distances of all candidates of the row, for the nearest-max_nbr selection
+      int k = 0;
+      pbc_visit(pos, c, n0, n1, i, r * r,
+                [&](int, int, int, int, float d2, float, float, float) { scratch_d2[cb + k++] = d2; });
+    }
+    int k = 0, o = 0;
+    pbc_visit(pos, c, n0, n1, i, r * r, [&](int j, int u, int v, int w, float d2, float ox, float oy, float oz) {
+      bool keep = true;
+      if (trunc) {  // rank = candidates strictly nearer, or equally near and earlier
+        int rank = 0;
+        for (int q = 0; q < ncand; ++q) {
+          const float dq = scratch_d2[cb + q];
+          rank += (dq < d2 || (dq == d2 && q < k)) ? 1 : 0;
+        }
+        keep = rank < max_nbr;
+      }
+      ++k;
+      if (keep && o < cnt) {
+        const int e = base + o++;
+        src[e] = j, dst[e] = i;
+        if (cell_offsets) cell_offsets[3 * e] = u, cell_offsets[3 * e + 1] = v, cell_offsets[3 * e + 2] = w;
+        offsets[3 * e] = ox, offsets[3 * e + 1] = oy, offsets[3 * e + 2] = oz;
+      }
+    });
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- CSR bookkeeping
 // ptr[g] = first i with seg_of[i] >= g (seg_of ascending), ptr[n_seg] = n; optional max segment length.
 __global__ __launch_bounds__(256) void segment_ptr_kernel(const int* __restrict__ seg_of, int n, int n_seg,
@@ -406,6 +511,28 @@ int eqf_radius_graph_fill(const float* pos, const int* mol_ptr, int n_mol, float
   if (n_mol <= 0) return 0;
   hipLaunchKernelGGL(radius_fill_kernel, dim3(n_mol), dim3(64), 0, (hipStream_t)stream, pos, mol_ptr, r * r, max_nbr,
                      row_ptr, src, dst);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_radius_graph_pbc_count(const float* pos, const float* cell, const int* mol_ptr, int n_mol, float r, int max_nbr,
+                               int* cand, int* deg, void* stream) {
+  if (!pos || !cell || !mol_ptr || !cand || !deg || max_nbr < 1 || !(r > 0.f)) return EQF_E_BADARG;
+  if (n_mol <= 0) return 0;
+  hipLaunchKernelGGL(pbc_count_kernel, dim3(n_mol), dim3(64), 0, (hipStream_t)stream, pos, cell, mol_ptr, r, max_nbr, cand,
+                     deg);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_radius_graph_pbc_fill(const float* pos, const float* cell, const int* mol_ptr, int n_mol, float r, int max_nbr,
+                              const int* row_ptr, const int* cand_ptr, float* scratch_d2, int* src, int* dst,
+                              int* cell_offsets, float* offsets, void* stream) {
+  if (!pos || !cell || !mol_ptr || !row_ptr || !cand_ptr || !scratch_d2 || !src || !dst || !offsets || max_nbr < 1)
+    return EQF_E_BADARG;
+  if (n_mol <= 0) return 0;
+  hipLaunchKernelGGL(pbc_fill_kernel, dim3(n_mol), dim3(64), 0, (hipStream_t)stream, pos, cell, mol_ptr, r, max_nbr,
+                     row_ptr, cand_ptr, scratch_d2, src, dst, cell_offsets, offsets);
   EQF_CHECK_LAUNCH();
   return 0;
 }

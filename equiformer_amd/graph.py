@@ -94,6 +94,46 @@ class EdgeGraph:
         return g
 
     @staticmethod
+    def from_radius_pbc(pos, cell, batch, r, max_num_neighbors=50, num_graphs=None):
+        """Periodic radius graph (ocpmodels radius_graph_pbc + get_pbc_distances semantics, see csrc/graph.hip).
+        Returns (graph, offsets[E,3] Cartesian, cell_offsets[E,3] int32); edges are dst-sorted."""
+        if not pos.is_cuda:
+            raise ops.HipOnlyError("radius graph construction runs on the GPU only")
+        pos = pos.detach().to(torch.float32).contiguous()
+        cell = cell.detach().to(torch.float32).contiguous().view(-1, 3, 3)
+        N = pos.shape[0]
+        if num_graphs is None:
+            num_graphs = int(cell.shape[0])
+        dev = pos.device
+        b32 = _i32(batch)
+        st = _stream()
+        stats = torch.empty(3, dtype=torch.int32, device=dev)  # [E, nodes of the largest structure, candidates]
+        mol_ptr = torch.empty(num_graphs + 1, dtype=torch.int32, device=dev)
+        call("eqf_segment_ptr", _P(b32), N, int(num_graphs), _P(mol_ptr), _P(stats, 4), st)
+        cand = torch.empty(N, dtype=torch.int32, device=dev)
+        deg = torch.empty(N, dtype=torch.int32, device=dev)
+        call("eqf_radius_graph_pbc_count", _P(pos), _P(cell), _P(mol_ptr), num_graphs, float(r), int(max_num_neighbors),
+             _P(cand), _P(deg), st)
+        row_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        cand_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        call("eqf_exclusive_scan_i32", _P(deg), N, _P(row_ptr), _P(stats), st)
+        call("eqf_exclusive_scan_i32", _P(cand), N, _P(cand_ptr), _P(stats, 8), st)
+        E, _, C = stats.tolist()  # the one host sync
+        src = torch.empty(E, dtype=torch.int32, device=dev)
+        dst = torch.empty(E, dtype=torch.int32, device=dev)
+        cell_offsets = torch.empty((E, 3), dtype=torch.int32, device=dev)
+        offsets = torch.empty((E, 3), dtype=torch.float32, device=dev)
+        scratch = torch.empty(max(C, 1), dtype=torch.float32, device=dev)
+        call("eqf_radius_graph_pbc_fill", _P(pos), _P(cell), _P(mol_ptr), num_graphs, float(r), int(max_num_neighbors),
+             _P(row_ptr), _P(cand_ptr), _P(scratch), _P(src), _P(dst), _P(cell_offsets), _P(offsets), st)
+        # a source can occur several times in a row (different images): generic by-source path
+        g = EdgeGraph(N, src, dst, row_ptr)
+        g.batch = b32
+        g.num_graphs = int(num_graphs)
+        g.mol_ptr = mol_ptr
+        return g, offsets, cell_offsets
+
+    @staticmethod
     def from_edges(edge_src, edge_dst, N, batch=None, num_graphs=None):
         """Arbitrary edge list (e.g. periodic-boundary edges computed upstream); sorted by dst here.
         Returns (graph, order) with order = permutation applied to the caller's per-edge data."""

@@ -3,8 +3,9 @@
 The reference registers the class in ocpmodels' registry as "graph_attention_transformer" and receives an ocpmodels
 `Batch`; ocpmodels is un-vendored, so the class is exposed here under the same name through this package's registry
 (`oc20_graph_attention_transformer`) and accepts any object with the same attributes
-(`pos, batch, atomic_numbers, tags, natoms` and, for periodic inputs, `edge_index` + per-edge Cartesian `offsets`
-as produced upstream by radius_graph_pbc / get_pbc_distances).  Auxiliary IS2RS head, attention head and
+(`pos, batch, atomic_numbers, tags, natoms`, and for periodic inputs either `cell` -- the neighbour search then runs
+on the GPU (`EdgeGraph.from_radius_pbc`, the `otf_graph=True` path of the YAML config) -- or a precomputed `edge_index` +
+per-edge Cartesian `offsets` as radius_graph_pbc / get_pbc_distances produce upstream).  Auxiliary IS2RS head, attention head and
 atom-edge attributes are not used by the `l1_256_nonlinear` config and are rejected.
 """
 import torch
@@ -53,10 +54,15 @@ class GraphAttentionTransformerOC20(_Trunk):
             if off is not None:
                 offsets = off.to(torch.float32)[order].contiguous()
         else:
+            # otf_graph [ref: _forward_otf_graph / _forward_use_pbc, :267-302]
             if self.use_pbc:
-                raise NotImplementedError("periodic neighbour search (ocpmodels radius_graph_pbc) is not on the hot "
-                                          "path yet: pass data.edge_index and data.offsets")
-            graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=self.max_neighbors)
+                cell = getattr(data, "cell", None)
+                if cell is None:
+                    raise ValueError("use_pbc=True needs data.cell ([B,3,3]) or precomputed data.edge_index / offsets")
+                graph, offsets, _ = EdgeGraph.from_radius_pbc(pos, cell, batch, self.max_radius,
+                                                              max_num_neighbors=self.max_neighbors)
+            else:
+                graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=self.max_neighbors)
         atom_embedding, _, _ = self.atom_embed(data.atomic_numbers.long())
         tag_embedding, _, _ = self.tag_embed(data.tags.long())
         return self._trunk_forward(atom_embedding + tag_embedding, pos, graph, offsets)

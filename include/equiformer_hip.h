@@ -80,6 +80,20 @@ int eqf_radius_graph_count(const float* pos, const int* mol_ptr, int n_mol, floa
 int eqf_radius_graph_fill(const float* pos, const int* mol_ptr, int n_mol, float r, int max_nbr,
                           const int* row_ptr, int* src, int* dst, void* stream);
 
+/* Periodic radius graph (OC20): for every centre i the neighbours (j, image n) of the same structure with
+ * 1e-4 < |pos_j + n.cell - pos_i|^2 <= r^2, images |n_k| <= ceil(r * |a_l x a_m| / |det cell|); at most max_nbr
+ * nearest per centre (ties in candidate order (j, n1, n2, n3)).  cell[n_mol,3,3] rows = lattice vectors.
+ * count: cand[N] = candidates per centre, deg[N] = min(cand, max_nbr).  fill: row_ptr / cand_ptr = exclusive scans
+ * of deg / cand, scratch_d2[sum cand] floats; writes the dst-sorted edge list src/dst[E], the integer images
+ * cell_offsets[E,3] (may be NULL) and their Cartesian offsets[E,3] (edge_vec = pos[src] - pos[dst] + offsets).
+ * [ref: ocpmodels radius_graph_pbc + get_pbc_distances as called at nets/graph_attention_transformer_oc20.py:267-293;
+ *  un-vendored dependency, algorithm restated in oracle/pbc.py] */
+int eqf_radius_graph_pbc_count(const float* pos, const float* cell, const int* mol_ptr, int n_mol, float r,
+                               int max_nbr, int* cand, int* deg, void* stream);
+int eqf_radius_graph_pbc_fill(const float* pos, const float* cell, const int* mol_ptr, int n_mol, float r,
+                              int max_nbr, const int* row_ptr, const int* cand_ptr, float* scratch_d2, int* src,
+                              int* dst, int* cell_offsets, float* offsets, void* stream);
+
 /* CSR bookkeeping of the graph (replaces torch.bincount / cumsum / argsort around the radius graph; the reference
  * gets the same quantities from torch_cluster / torch_scatter internals and `degree`,
  * nets/graph_attention_transformer.py:866-867,517).

@@ -137,6 +137,17 @@ def test_oc20_energy_parity():
     y = mod(data)
     print("oc20 energy rel %.3e (E=%d edges)" % (_rel(y, yr), src.numel()))
     assert _rel(y, yr) < 1e-4
+    # otf_graph=True / use_pbc=True (the YAML setting): the periodic neighbour search runs on the GPU from data.cell
+    from oracle import pbc
+    cells = torch.diag(cell)[None].repeat(B, 1, 1)
+    ei, coff, nb = pbc.radius_graph_pbc(pos, cells, [Na] * B, 5.0, 500)
+    _, _, offs = pbc.get_pbc_distances(pos.double(), ei, cells.double(), coff, nb)
+    yr2 = ref(Z, tags, pos.double(), batch, edge_index=ei, offsets=offs)
+    data2 = SimpleNamespace(pos=pos.to(dev), batch=batch.to(dev), atomic_numbers=Z.to(dev), tags=tags.to(dev),
+                            cell=cells.to(dev), natoms=torch.tensor([Na] * B, device=dev))
+    y2 = mod(data2)
+    print("oc20 otf-graph energy rel %.3e (E=%d edges)" % (_rel(y2, yr2), ei.shape[1]))
+    assert _rel(y2, yr2) < 1e-4
 
 
 @pytest.mark.parametrize("small", ["SMALL_L2", "SMALL_L3"])

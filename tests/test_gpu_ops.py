@@ -507,3 +507,36 @@ def test_attention_dropout_statistics():
     col = gv[:, 0]
     kept = (col > 0).float().mean().item()
     assert abs(kept - 0.8) < 0.02
+
+
+@pytest.mark.parametrize("max_nbr", [1000, 9])
+def test_radius_graph_pbc_matches_oracle(max_nbr):
+    """HIP periodic neighbour search vs the CPU restatement of ocpmodels' radius_graph_pbc (oracle/pbc.py): identical
+    edge sets (neighbour, centre, image), dst-sorted rows, Cartesian offsets = image . cell; with truncation the same
+    nearest-k survivors."""
+    from equiformer_amd.graph import EdgeGraph
+    from oracle import pbc
+    dev = _dev()
+    g0 = torch.Generator().manual_seed(21)
+    cell = torch.tensor([[[6.0, 0.0, 0.0], [1.5, 5.5, 0.0], [0.8, -1.1, 7.0]],
+                         [[4.0, 0.0, 0.0], [0.0, 9.0, 0.0], [0.0, 0.0, 12.0]],
+                         [[11.0, 0.0, 0.0], [0.0, 11.0, 0.0], [0.0, 0.0, 25.0]]])
+    natoms = [7, 5, 30]
+    frac = torch.rand(sum(natoms), 3, generator=g0)
+    pos = torch.cat([frac[:7] @ cell[0], frac[7:12] @ cell[1], frac[12:] @ cell[2]])
+    batch = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(natoms)])
+    r = 5.0
+    ei, off, nb = pbc.radius_graph_pbc(pos, cell, natoms, r, max_nbr)
+    g, offsets, cell_off = EdgeGraph.from_radius_pbc(pos.to(dev), cell.to(dev), batch.to(dev), r,
+                                                     max_num_neighbors=max_nbr)
+    assert g.E == ei.shape[1]
+    got = torch.cat([g.src.cpu().long()[:, None], g.dst.cpu().long()[:, None], cell_off.cpu().long()], dim=1)
+    want = torch.cat([ei[0][:, None], ei[1][:, None], off], dim=1)
+    assert torch.equal(got, want)  # same order as well: by centre, neighbour, image
+    cpe = torch.repeat_interleave(cell, nb, dim=0)
+    cart = torch.bmm(off.float().view(-1, 1, 3), cpe).view(-1, 3)
+    assert (offsets.cpu() - cart).abs().max() < 1e-5
+    rp = g.row_ptr.cpu().long()
+    assert torch.equal(rp[1:] - rp[:-1], torch.bincount(ei[1], minlength=sum(natoms)))
+    perm = g.src_perm.cpu().long()
+    assert torch.equal(perm, torch.argsort(ei[0], stable=True))

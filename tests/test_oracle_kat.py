@@ -161,3 +161,65 @@ def test_radius_graph_order():
     assert (dst[1:] >= dst[:-1]).all() and (batch[src] == batch[dst]).all() and (src != dst).all()
     same = dst[1:] == dst[:-1]
     assert (src[1:][same] > src[:-1][same]).all()
+
+
+# ---------------------------------------------------------------------------- periodic neighbour search (oracle/pbc.py)
+def test_pbc_lattice_coordination_numbers():
+    """Known answers: coordination shells of the simple-cubic and bcc lattices."""
+    from oracle import pbc
+    a = 3.0
+    cell = (torch.eye(3) * a)[None]
+    pos = torch.tensor([[0.3, 0.1, 0.7]])
+    for r, n in ((3.1, 6), (4.3, 18), (5.25, 26), (6.05, 32)):  # shells at a, a sqrt2, a sqrt3, 2a
+        ei, off, nb = pbc.radius_graph_pbc(pos, cell, [1], r, 1000)
+        assert ei.shape[1] == n == int(nb[0]) and (ei == 0).all()
+        _, dist, _ = pbc.get_pbc_distances(pos.double(), ei, cell.double(), off, nb)
+        assert dist.max() <= r and dist.min() >= a - 1e-9
+    # bcc: 8 neighbours at a sqrt3 / 2 = 2.598, 6 at a
+    pos2 = torch.tensor([[0.0, 0.0, 0.0], [1.5, 1.5, 1.5]])
+    ei, off, nb = pbc.radius_graph_pbc(pos2, cell, [2], 2.7, 1000)
+    assert ei.shape[1] == 16 and (ei[0] != ei[1]).all()
+    ei, off, nb = pbc.radius_graph_pbc(pos2, cell, [2], 3.05, 1000)
+    assert ei.shape[1] == 28
+    # exactly-on-the-cut-off pairs are kept (<=), unlike torch_cluster's strict <
+    ei, _, _ = pbc.radius_graph_pbc(pos, cell, [1], 3.0, 1000)
+    assert ei.shape[1] == 6
+
+
+def test_pbc_triclinic_matches_wide_enumeration_and_truncation():
+    from oracle import pbc
+    g = torch.Generator().manual_seed(11)
+    cell = torch.tensor([[[6.0, 0.0, 0.0], [1.5, 5.5, 0.0], [0.8, -1.1, 7.0]],
+                         [[4.0, 0.0, 0.0], [0.0, 9.0, 0.0], [0.0, 0.0, 12.0]]])
+    natoms = [7, 5]
+    frac = torch.rand(12, 3, generator=g)
+    pos = torch.cat([frac[:7] @ cell[0], frac[7:] @ cell[1]])
+    r = 5.0
+    ei, off, nb = pbc.radius_graph_pbc(pos, cell, natoms, r, 1000)
+    # independent enumeration over a fixed, generous image range
+    want = set()
+    start = 0
+    for b, n in enumerate(natoms):
+        rng = range(-4, 5)
+        for i in range(n):
+            for j in range(n):
+                for u in rng:
+                    for v in rng:
+                        for w in rng:
+                            d = pos[start + j] + torch.tensor([u, v, w], dtype=torch.float32) @ cell[b] - pos[start + i]
+                            d2 = float((d.double() ** 2).sum())
+                            if 1e-4 < d2 <= r * r:
+                                want.add((start + j, start + i, u, v, w))
+        start += n
+    got = {(int(ei[0, e]), int(ei[1, e]), *[int(x) for x in off[e]]) for e in range(ei.shape[1])}
+    assert got == want and int(nb.sum()) == len(want)
+    assert (ei[1][1:] >= ei[1][:-1]).all()
+    # truncation keeps the nearest max_neighbors of every centre
+    k = 9
+    ei2, off2, nb2 = pbc.radius_graph_pbc(pos, cell, natoms, r, k)
+    _, dist, _ = pbc.get_pbc_distances(pos.double(), ei, cell.double(), off, nb)
+    _, dist2, _ = pbc.get_pbc_distances(pos.double(), ei2, cell.double(), off2, nb2)
+    for i in range(12):
+        full = torch.sort(dist[ei[1] == i]).values
+        kept = torch.sort(dist2[ei2[1] == i]).values
+        assert kept.numel() == min(k, full.numel()) and torch.allclose(kept, full[:kept.numel()])
