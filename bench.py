@@ -47,19 +47,11 @@ def parse():
     return ap.parse_args()
 
 
-def make_optimizer(model, lr=5e-4, weight_decay=5e-3):
-    """AdamW with the reference's name-based no-weight-decay groups (optim_factory.py:27-42)."""
-    skip = model.no_weight_decay()
-    decay, no_decay = [], []
-    for name, p in model.named_parameters():
-        if (name.endswith(".bias") or name.endswith(".affine_weight") or name.endswith(".affine_bias")
-                or name.endswith(".mean_shift") or "bias." in name or name in skip):
-            no_decay.append(p)
-        else:
-            decay.append(p)
-    groups = [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
-    fused = all(p.is_cuda for p in model.parameters())
-    return torch.optim.AdamW(groups, lr=lr, fused=fused)
+def make_optimizer(model, lr=5e-4, weight_decay=5e-3, reducer=None):
+    """AdamW with the reference's name-based no-weight-decay groups (optim_factory.py:27-42,126-127), as the fused
+    flat-buffer HIP optimizer of equiformer_amd/optim.py (bit-for-bit torch.optim.AdamW semantics, tests/test_optim.py)."""
+    from equiformer_amd.optim import FlatAdamW, add_weight_decay
+    return FlatAdamW(add_weight_decay(model, weight_decay, model.no_weight_decay()), lr=lr, reducer=reducer)
 
 
 def cpu_baseline(args):
@@ -120,7 +112,7 @@ def main():
     model = nets.model_entrypoint(MODEL)(irreps_in="5x0e", radius=5.0, num_basis=128).to(dev).train()
     reducer = FlatGradAllReduce(model)
     reducer.broadcast_parameters()
-    opt = make_optimizer(model)
+    opt = make_optimizer(model, reducer=reducer if world > 1 else None)
     d = {k: v.to(dev) for k, v in qm9_like_batch(args.batch, args.atoms, side=args.side, seed=1000 + rank).items()}
 
     def step():

@@ -30,8 +30,11 @@ class RowLayout:
             off += mul * (2 * l + 1)
         self.dim = off
         self.c = lib.make_irreps(self.segs)
-        self.c_ref = ctypes.byref(self.c)
         self.num_irreps = irreps.num_irreps
+
+    @property
+    def c_ref(self):  # not stored: a byref object cannot be deep-copied / pickled (ModelEma deep-copies the model)
+        return ctypes.byref(self.c)
 
     def seg_index(self, l):
         for i, (_, ll) in enumerate(self.segs):
@@ -127,12 +130,15 @@ class DtpTable:
             for k in ("l1", "l2", "l3", "mul", "in_off", "out_off", "out_ch", "out_k", "w_off", "cg_off", "m_off"):
                 getattr(c, k)[i] = p[k]
         self.c = c
-        self.c_ref = ctypes.byref(c)
         self._cg_dev = {}
         self.key = (repr(self.layout_in.irreps), self.lmax_sh, repr(self.irreps_out))
         self.fusable = all(p["mul"] % 32 == 0 for p in paths)
         # every input segment is read by at least one path (then the backward writes all of dx)
         self.in_covered = {p["in_off"] for p in paths} == set(self.layout_in.offsets)
+
+    @property
+    def c_ref(self):
+        return ctypes.byref(self.c)
 
     def cg(self, device):
         t = self._cg_dev.get(device)

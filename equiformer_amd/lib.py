@@ -52,6 +52,8 @@ SIGNATURES = {
     "eqf_radius_graph_fill": [c_fp, c_fp, c_int, _f, c_int, c_fp, c_fp, c_fp, c_fp],
     "eqf_radius_graph_pbc_count": [c_fp, c_fp, c_fp, c_int, _f, c_int, c_fp, c_fp, c_fp],
     "eqf_radius_graph_pbc_fill": [c_fp, c_fp, c_fp, c_int, _f, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "eqf_sumsq": [c_fp, ctypes.c_long, c_fp, c_fp],
+    "eqf_adamw_step": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_long, _f, _f, _f, _f, c_int, _f, _f, c_fp],
     "eqf_segment_ptr": [c_fp, c_int, c_int, c_fp, c_fp, c_fp],
     "eqf_exclusive_scan_i32": [c_fp, c_int, c_fp, c_fp, c_fp],
     "eqf_csr_by_source": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp],

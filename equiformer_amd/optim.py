@@ -1,0 +1,151 @@
+"""Optimizer side of the train step on the GPU: AdamW over one flat fp32 buffer, gradient-norm clipping and the EMA of
+the weights fused into two HIP launches (csrc/optim.hip).
+
+Mirrors what the reference's drivers assemble around the hot path:
+  * `add_weight_decay` -- the name-based parameter groups of optim_factory.py:27-42 (biases, affine_weight / affine_bias,
+    mean_shift, ParameterList entries `bias.N` and `model.no_weight_decay()` names get weight_decay 0);
+  * `FlatAdamW` -- torch.optim.AdamW semantics (optim_factory.py:126-127) + `dispatch_clip_grad(mode='norm')`
+    (engine.py:76-78) + `ModelEmaV2.update` (engine.py:89-90, main_qm9.py:169-175), as ONE optimizer object.  It is a
+    torch.optim.Optimizer (param_groups with 'lr' for the schedulers, state_dict with exp_avg / exp_avg_sq / step per
+    parameter), but parameters, moments and the EMA copy live in flat buffers and a step is: one multi-tensor copy of
+    the gradients into the flat gradient buffer (skipped when `FlatGradAllReduce` already owns one), `eqf_sumsq` (only
+    when clipping) and `eqf_adamw_step` -- instead of ~230 parameter tensors x (AdamW + clip + EMA) element-wise ops.
+"""
+import copy
+import ctypes
+
+import torch
+
+from .lib import call
+
+
+def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
+    """[ref: optim_factory.py:27-42] -> [{'params': no_decay, 'weight_decay': 0.}, {'params': decay, ...}]"""
+    decay, no_decay = [], []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if (name.endswith(".bias") or name.endswith(".affine_weight") or name.endswith(".affine_bias")
+                or name.endswith(".mean_shift") or "bias." in name or name in skip_list):
+            no_decay.append(param)
+        else:
+            decay.append(param)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+def _P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    """AdamW (+ optional clip_grad_norm and EMA) on flat buffers.  `params`: iterable of tensors or param-group dicts
+    (every group may set its own weight_decay; lr / betas / eps must agree across groups, as in the reference's
+    drivers).  `reducer`: an `equiformer_amd.parallel.FlatGradAllReduce` over the same parameters whose flat gradient
+    buffer is then used directly.  `ema_decay`: keep an exponential moving average of the weights; `ema_module(model)`
+    returns a copy of `model` whose parameters alias it (what the drivers evaluate as `model_ema.module`)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, clip_grad=None,
+                 ema_decay=None, reducer=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.clip_grad = clip_grad
+        self.ema_decay = ema_decay
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if not ps:
+            raise ValueError("FlatAdamW got no parameters")
+        if any((not p.is_cuda) or p.dtype != torch.float32 for p in ps):
+            from .ops import HipOnlyError
+            raise HipOnlyError("FlatAdamW runs on GPU fp32 parameters only")
+        if reducer is not None:
+            if [id(p) for p in reducer.params] != [id(p) for p in self._ordered(ps, reducer.params)]:
+                raise ValueError("reducer and optimizer must hold the same parameters")
+            ps = list(reducer.params)  # adopt the reducer's layout
+        self._params = ps
+        self._reducer = reducer
+        dev = ps[0].device
+        self.sizes = [p.numel() for p in ps]
+        n = self.n = sum(self.sizes)
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_wd = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = reducer.flat if reducer is not None else torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_ema = None
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        wd_of = {id(p): g["weight_decay"] for g in self.param_groups for p in g["params"]}
+        off = 0
+        self._gviews = []
+        with torch.no_grad():
+            for p, k in zip(ps, self.sizes):
+                self.flat_p[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_p[off:off + k].view_as(p)  # the parameter now aliases the flat buffer
+                self.flat_wd[off:off + k].fill_(float(wd_of[id(p)]))
+                self._gviews.append(self.flat_g[off:off + k].view_as(p))
+                st = self.state[p]
+                st["step"] = 0
+                st["exp_avg"] = self.flat_m[off:off + k].view_as(p)
+                st["exp_avg_sq"] = self.flat_v[off:off + k].view_as(p)
+                off += k
+        if ema_decay is not None:
+            self.flat_ema = self.flat_p.clone()
+        self._step = 0
+
+    @staticmethod
+    def _ordered(ps, like):
+        ids = {id(p) for p in ps}
+        return [p for p in like if id(p) in ids]
+
+    def ema_module(self, model):
+        """Deep copy of `model` whose parameters are views of the EMA buffer (buffers are copied as they are)."""
+        if self.flat_ema is None:
+            raise RuntimeError("FlatAdamW was built without ema_decay")
+        m = copy.deepcopy(model)
+        by_id = {id(p): i for i, p in enumerate(self._params)}
+        offs = [0]
+        for k in self.sizes:
+            offs.append(offs[-1] + k)
+        for (_, src), (_, dst) in zip(model.named_parameters(), m.named_parameters()):
+            i = by_id.get(id(src))
+            if i is not None:
+                dst.data = self.flat_ema[offs[i]:offs[i + 1]].view_as(src)
+            dst.requires_grad_(False)
+        return m
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:
+            if g["lr"] != g0["lr"] or g["betas"] != g0["betas"] or g["eps"] != g0["eps"]:
+                raise ValueError("FlatAdamW: lr / betas / eps must agree across parameter groups")
+        # gradients -> flat buffer (already there when the reducer re-pointed .grad at its slices)
+        src, dst, zero = [], [], []
+        for p, v in zip(self._params, self._gviews):
+            if p.grad is None:
+                zero.append(v)
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if zero:
+            torch._foreach_zero_(zero)
+        if src:
+            torch._foreach_copy_(dst, src)
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream)
+        clip = self.clip_grad is not None
+        if clip:
+            call("eqf_sumsq", _P(self.flat_g), self.n, _P(self._sumsq), st)
+        self._step += 1
+        b1, b2 = g0["betas"]
+        call("eqf_adamw_step", _P(self.flat_p), _P(self.flat_g), _P(self.flat_m), _P(self.flat_v), _P(self.flat_wd),
+             _P(self.flat_ema), _P(self._sumsq) if clip else None, self.n, float(g0["lr"]), float(b1), float(b2),
+             float(g0["eps"]), self._step, float(self.clip_grad or 0.0), float(self.ema_decay or 0.0), st)
+        for p in self._params:
+            self.state[p]["step"] = self._step
+        return loss
+
+    def grad_norm(self):
+        """Global gradient norm of the last clipped step (device scalar, no sync)."""
+        return self._sumsq.sqrt()

@@ -339,6 +339,19 @@ int eqf_prof_enable(const char* filter);
  * into buf (host memory); clears the records.  Returns bytes written or < 0. */
 int eqf_prof_report(char* buf, int buflen);
 
+/* ---- optimizer step on one flat fp32 buffer (the step right after the hot path) -------------------------------
+ * eqf_sumsq: out[0] = sum g[i]^2 (zeroed here first) -- the global gradient norm of clip_grad_norm_
+ *   [ref: engine.py:76-78 dispatch_clip_grad(..., mode='norm')].
+ * eqf_adamw_step: torch.optim.AdamW update of p[n] from g[n] with state m, v (step = 1-based step count):
+ *   g *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) when sumsq != NULL; p *= 1 - lr*wd[i]; m = b1 m + (1-b1) g;
+ *   v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); wd[n] = per-element weight decay
+ *   (0 for the reference's no-decay names, optim_factory.py:27-42); when ema != NULL also
+ *   ema = ema_decay*ema + (1-ema_decay)*p  [ref: timm ModelEmaV2.update called at engine.py:89-90].              */
+int eqf_sumsq(const float* g, long n, float* out, void* stream);
+int eqf_adamw_step(float* p, const float* g, float* m, float* v, const float* wd, float* ema, const float* sumsq,
+                   long n, float lr, float beta1, float beta2, float eps, int step, float max_norm, float ema_decay,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

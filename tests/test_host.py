@@ -185,3 +185,16 @@ def test_synthetic_batches_have_the_survey_statistics():
     assert 320 < src.numel() / 2 <= 420
     dmin = torch.cdist(a["pos"][:21], a["pos"][:21]) + 10 * torch.eye(21)
     assert dmin.min() > 0.7
+
+
+def test_model_can_be_deep_copied_and_pickled():
+    """The drivers deep-copy the model for the EMA (timm ModelEma, main_qm9.py:169-175) and torch.save whole models."""
+    import copy
+    import io
+    from equiformer_amd import nets
+    m = nets.model_entrypoint("graph_attention_transformer_nonlinear_l2")(irreps_in="5x0e", radius=5.0, num_basis=32)
+    m2 = copy.deepcopy(m)
+    assert [n for n, _ in m.named_parameters()] == [n for n, _ in m2.named_parameters()]
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    assert buf.tell() > 0
