@@ -760,11 +760,16 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
     const int nchunk = (Ncat + B_KC - 1) / B_KC;
     auto chunk = [&](auto ctag) __attribute__((always_inline)) {  // one 32-channel chunk: MFMA loop + register epilogue
       constexpr int c = decltype(ctag)::value;
-      f32x4 acc[2][D3];
+      // two accumulators per row tile only where a single dependent chain would stall the matrix pipe (D3 == 1);
+      // with D3 >= 3 the row tiles themselves are independent chains and the second set only costs registers
+      constexpr int NACC = (D3 == 1) ? 2 : 1;
+      f32x4 acc[NACC][D3];
 #pragma unroll
       for (int i = 0; i < D3; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[0][i][q] = 0.f, acc[1][i][q] = 0.f;
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int a_ = 0; a_ < NACC; ++a_) acc[a_][i][q] = 0.f;
       float wv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -852,7 +857,8 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
               for (int rt = 0; rt < D3; ++rt)
-                acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[jj][rt], b0[jj], acc[jj & 1][rt], 0, 0, 0);
+                acc[jj & (NACC - 1)][rt] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(aA[jj][rt], b0[jj], acc[jj & (NACC - 1)][rt], 0, 0, 0);
             ap += 32 * SD;  // after the last block of the chunk this points past the tile: the reads below are then
                             // of in-bounds LDS garbage that is never used
 #pragma unroll
@@ -865,7 +871,8 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
               for (int rt = 0; rt < D3; ++rt)
-                acc[jj & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[jj][rt], b1[jj], acc[jj & 1][rt], 0, 0, 0);
+                acc[jj & (NACC - 1)][rt] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(aB[jj][rt], b1[jj], acc[jj & (NACC - 1)][rt], 0, 0, 0);
           };
           int kb = kb0;
 #pragma unroll 1
@@ -891,7 +898,7 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
         const float* mp = mrow + q * mt_len + P.mt_off;
 #pragma unroll
         for (int m3 = 0; m3 < D3; ++m3) {
-          const float dm = acc[0][m3][q] + acc[1][m3][q];
+          const float dm = (NACC == 2) ? acc[0][m3][q] + acc[NACC - 1][m3][q] : acc[0][m3][q];
           const float dmw = dm * wv[q];
           float tm = 0.f;
 #pragma unroll
