@@ -331,7 +331,7 @@ class SeparableFCTP(nn.Module):
     def folded_lin_weight(self):
         """lin weight with the shared depth-wise weights folded into its rows:
         Linear(DTP_w(x)) == Linear'(DTP_1(x)) with W'[(p,u), :] = w[p,u] * W[(p,u), :]."""
-        scale = self.dtp.tp.weight[self._row_to_w]
+        scale = self.dtp.tp.weight.index_select(0, self._row_to_w)
         chunks, r = [], 0
         for (l, _, K, _, N, w_off) in self.lin.spec.pairs:
             W = self.lin.tp.weight[w_off:w_off + K * N].view(K, N)
@@ -343,7 +343,9 @@ class SeparableFCTP(nn.Module):
         """Flat lin weight ([K(l), N(l)] blocks, ascending degree) with the shared depth-wise weights
         (internal_weights=True) folded into the rows: two element-wise kernels instead of per-degree slicing."""
         if self.dtp.tp.internal_weights:
-            return self.lin.tp.weight * self.dtp.tp.weight[self._elem_to_w]
+            # index_select, not weight[idx]: the backward of advanced indexing is index_put_(accumulate=True), which
+            # sorts the 64 512 indices on the device (45 rocPRIM launches per block); index_select's is one index_add_
+            return self.lin.tp.weight * self.dtp.tp.weight.index_select(0, self._elem_to_w)
         return self.lin.tp.weight
 
     def forward(self, node_input, ectx, use_fused=True):
