@@ -382,9 +382,6 @@ class GraphAttention(nn.Module):
         self.num_heads = num_heads
         self.rescale_degree = rescale_degree
         self.nonlinear_message = nonlinear_message
-        if not nonlinear_message:
-            raise NotImplementedError("the MI355X hot path implements the non-linear message variant "
-                                      "(every BASELINE config); linear-message models are a follow-up")
         if rescale_degree:
             raise NotImplementedError("rescale_degree=True is not used by any registered model")
         if proj_drop != 0.0:
@@ -398,15 +395,39 @@ class GraphAttention(nn.Module):
         self.mul_alpha_head = mul_alpha // num_heads
         irreps_alpha = Irreps("{}x0e".format(mul_alpha))
 
-        self.sep_act = SeparableFCTP(self.irreps_pre_attn, self.irreps_edge_attr, self.irreps_pre_attn, fc_neurons,
-                                     use_activation=True, norm_layer=None, internal_weights=False)
-        self.sep_alpha = LinearRS(self.sep_act.dtp.table.irreps_out, irreps_alpha)
-        self.sep_value = SeparableFCTP(self.irreps_pre_attn, self.irreps_edge_attr, irreps_attn_heads, fc_neurons=None,
-                                       use_activation=False, norm_layer=None, internal_weights=True)
-        self.alpha_fused_spec = (ops.DtpLinearSpec(self.sep_act.dtp.table, self.sep_alpha.layout_out)
-                                 if self.sep_act.dtp.table.fusable else None)
-        # value linear + attention-logit linear share ONE generation of the DTP output (concatenated degree-0 weight)
-        self.act_sfc_spec = ops.SfcSpec(self.sep_act.dtp.table, self.sep_act.lin.layout_out, n2=mul_alpha)
+        if nonlinear_message:
+            self.sep_act = SeparableFCTP(self.irreps_pre_attn, self.irreps_edge_attr, self.irreps_pre_attn, fc_neurons,
+                                         use_activation=True, norm_layer=None, internal_weights=False)
+            self.sep_alpha = LinearRS(self.sep_act.dtp.table.irreps_out, irreps_alpha)
+            self.sep_value = SeparableFCTP(self.irreps_pre_attn, self.irreps_edge_attr, irreps_attn_heads,
+                                           fc_neurons=None, use_activation=False, norm_layer=None,
+                                           internal_weights=True)
+            self.alpha_fused_spec = (ops.DtpLinearSpec(self.sep_act.dtp.table, self.sep_alpha.layout_out)
+                                     if self.sep_act.dtp.table.fusable else None)
+            # value linear + attention-logit linear share ONE generation of the DTP output (concatenated degree-0
+            # weight)
+            self.act_sfc_spec = ops.SfcSpec(self.sep_act.dtp.table, self.sep_act.lin.layout_out, n2=mul_alpha)
+        else:
+            # linear messages [ref: nets/graph_attention_transformer.py:459-465,497-502]: ONE SeparableFCTP whose
+            # output irreps are (alpha scalars + head irreps).simplify(); Vec2AttnHeads then cuts the scalar segment
+            # into per-head runs [alpha (mul_alpha_head) | value scalars].  The same fused kernel serves it: the
+            # columns of the degree-0 weight are split into the value part (main consumer) and the alpha part (second
+            # consumer), a gather on a [K, 256] parameter per call instead of a permutation of per-edge data.
+            irreps_attn_all = _simplified_sorted(irreps_alpha + irreps_attn_heads)
+            self.sep = SeparableFCTP(self.irreps_pre_attn, self.irreps_edge_attr, irreps_attn_all, fc_neurons,
+                                     use_activation=False, norm_layer=None, internal_weights=False)
+            n0 = sum(m for m, ir in irreps_attn_all if ir.l == 0)
+            hw = n0 // num_heads
+            mah = self.mul_alpha_head
+            self.register_buffer("_idx_alpha", torch.tensor([h * hw + k for h in range(num_heads) for k in range(mah)],
+                                                            dtype=torch.long), persistent=False)
+            self.register_buffer("_idx_value", torch.tensor([h * hw + mah + k for h in range(num_heads)
+                                                             for k in range(hw - mah)], dtype=torch.long),
+                                 persistent=False)
+            self.lin_sfc_spec = ops.SfcSpec(self.sep.dtp.table, RowLayout(irreps_attn_heads), n2=mul_alpha)
+            if not self.lin_sfc_spec.supported:
+                raise NotImplementedError("linear-message attention needs the fused SeparableFCTP kernels "
+                                          "(channel counts in multiples of 32)")
         self.heads_layout = RowLayout(irreps_attn_heads)
 
         self.alpha_dot = nn.Parameter(torch.randn(1, num_heads, self.mul_alpha_head))
@@ -422,6 +443,20 @@ class GraphAttention(nn.Module):
                 batch=None, ectx=None, **kwargs):
         g = ectx.graph
         message = ops.gather_add(self.merge_src(node_input), self.merge_dst(node_input), g)
+        if not self.nonlinear_message:
+            value, alpha = self._linear_message(message, ectx)
+        else:
+            value, alpha = self._nonlinear_message(message, ectx)
+        logit = ops.alpha_logits(alpha, self.alpha_dot, self.num_heads, self.mul_alpha_head,
+                                 so3.C_SMOOTH_LEAKY_RELU_02)
+        drop_p, seed = 0.0, 0
+        if self.training and self.alpha_drop > 0.0:
+            drop_p = self.alpha_drop
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+        attn = ops.attn_aggregate(logit, value, g, self.num_heads, self.heads_layout, drop_p, seed)
+        return self.proj(attn)
+
+    def _nonlinear_message(self, message, ectx):
         sa = self.sep_act
         table = sa.dtp.table
         M = ectx.coupling(table)
@@ -439,14 +474,22 @@ class GraphAttention(nn.Module):
             value = sa.lin(mid)
         value = sa.gate(value)
         value = self.sep_value(value, ectx, use_fused=self.use_fused)
-        logit = ops.alpha_logits(alpha, self.alpha_dot, self.num_heads, self.mul_alpha_head,
-                                 so3.C_SMOOTH_LEAKY_RELU_02)
-        drop_p, seed = 0.0, 0
-        if self.training and self.alpha_drop > 0.0:
-            drop_p = self.alpha_drop
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
-        attn = ops.attn_aggregate(logit, value, g, self.num_heads, self.heads_layout, drop_p, seed)
-        return self.proj(attn)
+        return value, alpha
+
+    def _linear_message(self, message, ectx):
+        sep = self.sep
+        table = sep.dtp.table
+        M = ectx.coupling(table)
+        weight = sep.dtp_rad(ectx.edge_scalars)
+        W = sep.lin.tp.weight
+        (l, _, K0, _, N0, off0) = sep.lin.spec.pairs[0]
+        assert l == 0 and off0 == 0
+        W0 = W[:K0 * N0].view(K0, N0)
+        w_main = torch.cat([W0.index_select(1, self._idx_value).reshape(-1), W[K0 * N0:]])
+        w_alpha = W0.index_select(1, self._idx_alpha).reshape(-1)
+        b = sep.lin._bias()
+        return ops.sep_fctp(message, M, weight, w_main, b.index_select(0, self._idx_value), self.lin_sfc_spec,
+                            weight2=w_alpha, bias2=b.index_select(0, self._idx_alpha))
 
 
 class FeedForwardNetwork(nn.Module):

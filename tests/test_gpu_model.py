@@ -64,6 +64,26 @@ def test_qm9_forward_backward_parity():
     print("worst parameter-gradient rel err %.3e" % worst)
 
 
+def test_qm9_linear_message_variant_parity():
+    """`graph_attention_transformer_l2` (nonlinear_message=False, reference :459-465,497-502): forward and parameter
+    gradients against the oracle on a small batch."""
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = _dev()
+    ref, mod = _pair("graph_attention_transformer_l2", onets.graph_attention_transformer_l2, "5x0e", num_basis=32)
+    d = qm9_like_batch(3, 12, side=5.0, seed=7)
+    ref = ref.double()
+    yr = ref(None, d["pos"].double(), d["batch"], d["z"])
+    y = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
+    print("linear-message variant: rel err %.3e" % _rel(y, yr))
+    assert _rel(y, yr) < 1e-4
+    gr = torch.autograd.grad((yr.squeeze() - d["y"].double()).abs().mean(), list(ref.parameters()), allow_unused=True)
+    gg = torch.autograd.grad((y.squeeze() - d["y"].to(dev)).abs().mean(), list(mod.parameters()), allow_unused=True)
+    for (n, _), a, r in zip(ref.named_parameters(), gg, gr):
+        assert (a is None) == (r is None), n
+        if r is not None and r.abs().max() > 0:
+            assert _rel(a, r) < 2e-3, (n, _rel(a, r))
+
+
 def test_qm9_train_step_runs_and_reduces_loss():
     from equiformer_amd import nets
     from equiformer_amd.synthetic import qm9_like_batch

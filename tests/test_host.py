@@ -48,8 +48,8 @@ def test_registry_and_factories():
     with pytest.raises(KeyError):
         nets.model_entrypoint("no_such_model")
     # variants outside the hot path fail loudly instead of silently degrading
-    with pytest.raises(NotImplementedError):
-        nets.model_entrypoint("graph_attention_transformer_l2")("5x0e", 5.0)
+    m = nets.model_entrypoint("graph_attention_transformer_l2")("5x0e", 5.0)  # linear-message variant is built
+    assert sum(p.numel() for p in m.parameters()) == 3008515 and hasattr(m.blocks[0].ga, "sep")
     with pytest.raises(NotImplementedError):
         nets.model_entrypoint("graph_attention_transformer_nonlinear_bessel_l2")("5x0e", 5.0)
     with pytest.raises(NotImplementedError):
