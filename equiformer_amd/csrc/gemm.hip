@@ -22,6 +22,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+int g_gemm_exp = 0;
+
 namespace {
 
 constexpr int BK = 32;
@@ -63,6 +65,15 @@ struct DtpA {
 template <int BX, int SX>
 struct LoaderContigK {
   float4 v[BX / 32];
+  long roff[BX / 32];  // row offsets of this thread's rows: the same for every K step, computed once (init)
+  __device__ __forceinline__ void init(const Rows& R, int x0, int xcnt) {
+    const int xr0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int pass = 0; pass < BX / 32; ++pass) {
+      const int xr = xr0 + pass * 32;
+      roff[pass] = row_off2(x0 + (xr < xcnt ? xr : 0), R.d, R.ld, R.inner);
+    }
+  }
   __device__ __forceinline__ void issue(const Rows& R, int x0, int xcnt, int k0, int K, bool vec) {
     const int t = threadIdx.x;
     const int kq = t & 7, xr0 = t >> 3;
@@ -72,7 +83,7 @@ struct LoaderContigK {
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
       const int krem = K - (k0 + kq * 4);
       if (xr < xcnt && krem > 0) {
-        const float* p = R.base + row_off2(x0 + xr, R.d, R.ld, R.inner) + k0 + kq * 4;
+        const float* p = R.base + roff[pass] + k0 + kq * 4;
         if (vec && krem >= 4) {
           r = *reinterpret_cast<const float4*>(p);
         } else {
@@ -223,6 +234,7 @@ struct RowsArgs {
   int rows_per_tile;
   int accumulate;
   int vecA, vecB;
+  int exp;  // development aid (eqf_gemm_debug_exp): 1 no stores, 2 no MFMA
   DtpA dtp;
 };
 
@@ -236,6 +248,7 @@ struct RowsP {  // one problem of a grouped launch (A operand from memory)
   int rows_per_tile;
   int accumulate;
   int vecA, vecB;
+  int exp;
 };
 constexpr int MAX_GROUP = 4;
 struct RowsGroup {
@@ -279,12 +292,15 @@ __device__ __forceinline__ void gemm_rows_body(const ArgsT& g, const int bx, con
     stage_coupling(Mt, g.dtp, e0, ecnt);
     ld.issue(g.dtp, 0, e0, ecnt);
   } else {
+    la.init(g.A, m0, mcnt);
     la.issue(g.A, m0, mcnt, 0, g.K, g.vecA);
   }
-  if (BMODE == B_KN)
+  if (BMODE == B_KN) {
     lbn.issue(g.B, 0, min(BK, g.K), n0, g.N, g.vecB);
-  else
+  } else {
+    lbk.init(g.B, n0, ncnt);
     lbk.issue(g.B, n0, ncnt, 0, g.K, g.vecB);
+  }
   if (AMODE == A_DTP) __syncthreads();  // coupling tile visible
 
   for (int k0 = 0; k0 < g.K; k0 += BK) {
@@ -308,14 +324,29 @@ __device__ __forceinline__ void gemm_rows_body(const ArgsT& g, const int bx, con
       else
         lbk.issue(g.B, n0, ncnt, k1, g.K, g.vecB);
     }
-    mma_step<TM, TN, SA, SB>(As, Bs, wm0, wn0, 0, BK, acc);
+    if (!(g.exp & 2)) mma_step<TM, TN, SA, SB>(As, Bs, wm0, wn0, 0, BK, acc);
     __syncthreads();
   }
+  if (g.exp & 1) return;
 
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hi = lane >> 5;
+  const bool flat_c = g.C.d == 1;  // wave-uniform: plain rows need no two-level split
+  const SmallDiv cdiv(g.C.d);
+  float* const cbase = const_cast<float*>(g.C.base);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    // rows of this lane in the 32-row tile: rb + (q & 3) + 8 (q >> 2); one exact division for rb, SmallDiv for the rest
+    const int rb = wm0 + i * 32 + 4 * hi;
+    long off0;
+    int rem0 = 0;
+    if (flat_c) {
+      off0 = (long)(m0 + rb) * g.C.ld;
+    } else {
+      const int qb = (m0 + rb) / g.C.d;
+      rem0 = (m0 + rb) - qb * g.C.d;
+      off0 = (long)qb * g.C.ld;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn0 + j * 32 + r;
@@ -323,15 +354,23 @@ __device__ __forceinline__ void gemm_rows_body(const ArgsT& g, const int bx, con
       const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int row = wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;
-        if (row < mcnt) {
-          float* p = const_cast<float*>(g.C.base) + row_off2(m0 + row, g.C.d, g.C.ld, g.C.inner) + col;
+        const int dr = (q & 3) + 8 * (q >> 2);
+        if (rb + dr < mcnt) {
+          long off;
+          if (flat_c) {
+            off = off0 + (long)dr * g.C.ld;
+          } else {
+            const int t = rem0 + dr, dq = cdiv.div(t);
+            off = off0 + (long)dq * g.C.ld + (long)(t - dq * g.C.d) * g.C.inner;
+          }
+          float* p = cbase + off + col;
           float v = acc[i][j][q] + bv;
           if (g.accumulate) v += *p;
           *p = v;
         }
       }
     }
+  }
 }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
@@ -506,7 +545,7 @@ void launch_rows_cfg(const RowsArgs& a, hipStream_t st) {
 template <int AMODE, int BMODE>
 int launch_rows(RowsArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return 0;
-  const int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+  const int bn = (a.N > 64 && !(g_gemm_exp & 4)) ? 128 : (a.N > 32 ? 64 : 32);
   // 64-row tiles when 128-row tiles would leave most of the 256 CUs without a workgroup
   const int d = AMODE == A_DTP ? a.dtp.d3 : 1;
   const long tiles128 = (long)eqf_cdiv(a.M, (128 / d) * d) * eqf_cdiv(a.N, bn);
@@ -519,6 +558,7 @@ int launch_rows(RowsArgs& a, hipStream_t st) {
   } else {
     a.rows_per_tile = bm;
   }
+  a.exp = g_gemm_exp;
   char name[96];
   snprintf(name, sizeof name, "gemm_rows_%dx%d_%s_%s", bm, bn, AMODE == A_DTP ? "dtp" : "mem",
            BMODE == B_KN ? "kn" : "nk");
@@ -631,6 +671,11 @@ int build_dtp(const eqf_dtp_paths* P, int l3, const float* x, const float* coupl
 
 extern "C" {
 
+int eqf_gemm_debug_exp(int mask) {
+  g_gemm_exp = mask;
+  return 0;
+}
+
 int eqf_gemm_nn(const float* A, eqf_rows ra, const float* B, int ldb, float* C, eqf_rows rc, const float* bias, int M,
                 int N, int K, int accumulate, void* stream) {
   if (!A || !B || !C || ra.d < 1 || rc.d < 1) return EQF_E_BADARG;
@@ -692,6 +737,7 @@ int eqf_gemm_group(const eqf_gemm_desc* d, int n, void* stream) {
       P.M = d[i].M, P.N = d[i].N, P.K = d[i].K, P.accumulate = d[i].accumulate;
       P.vecA = rows_vec_ok(d[i].A, d[i].ra);
       P.vecB = aligned16(d[i].B) && d[i].ldb % 4 == 0;
+      P.exp = 0;
       P.rows_per_tile = 64;
       if (P.N > 32) bn_need = 64;
       flops += 2.0 * P.M * (double)P.N * P.K;
