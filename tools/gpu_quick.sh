@@ -1,4 +1,7 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2u; export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q 2>&1 | tail -3
-timeout 300 python tools/gemm_exp.py 2>&1 | grep -v amdgpu | tee gpurun_out/r2u/gemm_exp2.txt
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-230
+cd $GRAFT_REPO_ROOT; OUT=$GRAFT_REPO_ROOT/gpurun_out/r2v; mkdir -p $OUT; export TMPDIR=/tmp
+cd /tmp
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $GRAFT_REPO_ROOT/tools/bench_sfc.py 25354 > $OUT/fetch.log 2>&1; echo "fetch rc=$?"
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $GRAFT_REPO_ROOT/tools/bench_sfc.py 25354 > $OUT/write.log 2>&1; echo "write rc=$?"
+cd $GRAFT_REPO_ROOT
+find $OUT -name "*counter_collection.csv" | head; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+python tools/pmc_traffic.py $OUT $OUT/pmc_dominant.json

@@ -41,32 +41,21 @@ def kernel_bytes(k):
 
 
 res = {}
-names = {"sfc_fwd": ["fwd_kernel<5>"], "sfc_bwd_data": ["bwd_kernel<5>"],
+names = {"sfc_fwd": [k for k in vals if k.startswith("fwd_kernel")],
+         "sfc_bwd_data": [k for k in vals if k.startswith("bwd_kernel")],
          "sfc_wgrad": [k for k in vals if k.startswith("wgrad_kernel")]}
 for prof_name, kernels in names.items():
     tot = {"sep_act": 0.0, "sep_value": 0.0}
     detail = {}
     for k in kernels:
-        if k not in vals:
-            continue
         kb = kernel_bytes(k)
         detail[k] = kb
         for shape in tot:
-            # wgrad classes that only one shape launches show up with (nearly) equal halves of the same shape; both
-            # halves are then that shape's launches and the split is harmless for the 6:7 mean
             tot[shape] += kb[shape]["fetch"] + kb[shape]["write"]
-    if prof_name == "sfc_wgrad":
-        # the column-tile classes are launched by different shapes: take the plain mean over the two shapes' calls
-        ncalls = len(vals["fwd_kernel<5>"]["FETCH_SIZE"])
-        total = sum(2 * 1024 * v for k in kernels for _, v in vals[k]["FETCH_SIZE"]) + \
-            sum(1024 * v for k in kernels for _, v in vals[k]["WRITE_SIZE"])
-        res[prof_name] = {"hbm_bytes_per_launch": total / ncalls, "detail": detail,
-                          "note": "sum over the class kernels of one eqf_sfc_bwd_weight call, mean over both shapes; "
-                                  "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes"}
-        continue
     res[prof_name] = {"hbm_bytes_per_launch": (6 * tot["sep_act"] + 7 * tot["sep_value"]) / 13.0,
                       "per_shape_bytes": tot, "detail": detail,
-                      "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes"}
+                      "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes; "
+                              "mean over a train step's 6 sep_act- and 7 sep_value-shaped launches"}
 json.dump(res, open(out, "w"), indent=1)
 for k, v in res.items():
     print("%-14s %.1f MB / launch" % (k, v["hbm_bytes_per_launch"] / 1e6), v.get("per_shape_bytes", ""))
