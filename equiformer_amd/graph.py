@@ -23,7 +23,7 @@ def _ptr_from_counts(counts):
 
 
 def _P(t, byte_offset=0):
-    return ctypes.c_void_p(t.data_ptr() + byte_offset) if t is not None else None
+    return ctypes.c_void_p(ops._nonnull(t) + byte_offset) if t is not None else None
 
 
 def _stream():

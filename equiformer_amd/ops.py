@@ -20,10 +20,25 @@ class HipOnlyError(RuntimeError):
     pass
 
 
+_dummy = {}
+
+
+def _nonnull(t):
+    """Device address of a tensor; an EMPTY tensor (a batch without any edge) has data_ptr() == 0, which the C ABI would
+    reject as a missing argument before it looks at the (zero) row count: hand it a valid one-element buffer instead."""
+    a = t.data_ptr()
+    if a == 0 and t.is_cuda:
+        d = _dummy.get(t.device)
+        if d is None:
+            d = _dummy[t.device] = torch.zeros(64, dtype=torch.float32, device=t.device)
+        return d.data_ptr()
+    return a
+
+
 def _p(t, off=0):
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr() + 4 * off)
+    return ctypes.c_void_p(_nonnull(t) + 4 * off)
 
 
 def _stream():
