@@ -309,6 +309,97 @@ __global__ void attn_fwd_kernel(const float* __restrict__ logit, const float* __
     if (col4[s] >= 0) reinterpret_cast<float4*>(out)[(long)n * D4 + col4[s]] = acc[s];
 }
 
+// Heads of <= 32 float4 groups (QM9 / MD17: 30): a wave covers TWO edges per step (lanes 0-31 edge e, lanes 32-63 edge
+// e+1) and two such steps are issued before the first FMA -- four independent 16-byte value loads per lane in flight
+// instead of one with 30 of 64 lanes working; the halves are folded with one shuffle at the end.
+__global__ void attn_fwd_half_kernel(const float* __restrict__ logit, const float* __restrict__ value,
+                                     const int* __restrict__ row_ptr, float* __restrict__ alpha,
+                                     float* __restrict__ out, const HeadTab T, float drop_p, unsigned long long seed) {
+  const int n = blockIdx.x;
+  const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, gl = lane & 31;
+  const int beg = row_ptr[n], end = row_ptr[n + 1];
+  const int H = T.H, D4 = T.D >> 2;
+  const int col4 = (gl < T.G) ? head_col(T, h, gl) >> 2 : -1;
+  float mx = -INFINITY;
+  for (int e = beg + lane; e < end; e += 64) mx = fmaxf(mx, logit[(long)e * H + h]);
+  mx = wave_max(mx);
+  float sm = 0.f;
+  for (int e = beg + lane; e < end; e += 64) sm += __expf(logit[(long)e * H + h] - mx);
+  sm = wave_sum(sm);
+  const float inv = 1.f / (sm + 1e-16f);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e0 = beg; e0 < end; e0 += 4) {
+    const int ea = e0 + half, eb = e0 + 2 + half;
+    const bool va = ea < end, vb = eb < end;
+    const float la = va ? logit[(long)ea * H + h] : 0.f, lb = vb ? logit[(long)eb * H + h] : 0.f;
+    const float4 xa = (va && col4 >= 0) ? reinterpret_cast<const float4*>(value)[(long)ea * D4 + col4] : z4;
+    const float4 xb = (vb && col4 >= 0) ? reinterpret_cast<const float4*>(value)[(long)eb * D4 + col4] : z4;
+    const float aa = va ? __expf(la - mx) * inv : 0.f, ab = vb ? __expf(lb - mx) * inv : 0.f;
+    if (gl == 0) {
+      if (va) alpha[(long)ea * H + h] = aa;
+      if (vb) alpha[(long)eb * H + h] = ab;
+    }
+    const float ka = aa * keep_scale(seed, (unsigned long long)ea * H + h, drop_p);
+    const float kb = ab * keep_scale(seed, (unsigned long long)eb * H + h, drop_p);
+    acc.x = fmaf(ka, xa.x, acc.x), acc.y = fmaf(ka, xa.y, acc.y), acc.z = fmaf(ka, xa.z, acc.z), acc.w = fmaf(ka, xa.w, acc.w);
+    acc.x = fmaf(kb, xb.x, acc.x), acc.y = fmaf(kb, xb.y, acc.y), acc.z = fmaf(kb, xb.z, acc.z), acc.w = fmaf(kb, xb.w, acc.w);
+  }
+  acc.x += __shfl_xor(acc.x, 32), acc.y += __shfl_xor(acc.y, 32);
+  acc.z += __shfl_xor(acc.z, 32), acc.w += __shfl_xor(acc.w, 32);
+  if (half == 0 && col4 >= 0) reinterpret_cast<float4*>(out)[(long)n * D4 + col4] = acc;
+}
+
+__global__ void attn_bwd_half_kernel(const float* __restrict__ alpha, const float* __restrict__ value,
+                                     const int* __restrict__ row_ptr, const float* __restrict__ d_out,
+                                     float* __restrict__ d_value, float* __restrict__ d_logit, const HeadTab T,
+                                     float drop_p, unsigned long long seed) {
+  const int n = blockIdx.x;
+  const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, gl = lane & 31;
+  const int beg = row_ptr[n], end = row_ptr[n + 1];
+  const int H = T.H, D4 = T.D >> 2;
+  const int col4 = (gl < T.G) ? head_col(T, h, gl) >> 2 : -1;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 go = (col4 >= 0) ? reinterpret_cast<const float4*>(d_out)[(long)n * D4 + col4] : z4;
+  float s_acc = 0.f;
+  for (int e0 = beg; e0 < end; e0 += 4) {
+    const int ea = e0 + half, eb = e0 + 2 + half;
+    const bool va = ea < end, vb = eb < end;
+    const float aa = va ? alpha[(long)ea * H + h] : 0.f, ab = vb ? alpha[(long)eb * H + h] : 0.f;
+    const float4 xa = (va && col4 >= 0) ? reinterpret_cast<const float4*>(value)[(long)ea * D4 + col4] : z4;
+    const float4 xb = (vb && col4 >= 0) ? reinterpret_cast<const float4*>(value)[(long)eb * D4 + col4] : z4;
+    const float keepa = keep_scale(seed, (unsigned long long)ea * H + h, drop_p);
+    const float keepb = keep_scale(seed, (unsigned long long)eb * H + h, drop_p);
+    float pa = xa.x * go.x + xa.y * go.y + xa.z * go.z + xa.w * go.w;
+    float pb = xb.x * go.x + xb.y * go.y + xb.z * go.z + xb.w * go.w;
+    if (va && col4 >= 0) {
+      const float k = aa * keepa;
+      reinterpret_cast<float4*>(d_value)[(long)ea * D4 + col4] = make_float4(k * go.x, k * go.y, k * go.z, k * go.w);
+    }
+    if (vb && col4 >= 0) {
+      const float k = ab * keepb;
+      reinterpret_cast<float4*>(d_value)[(long)eb * D4 + col4] = make_float4(k * go.x, k * go.y, k * go.z, k * go.w);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) pa += __shfl_xor(pa, o), pb += __shfl_xor(pb, o);  // sums inside each half
+    const float da = pa * keepa, db = pb * keepb;
+    float contrib = aa * da + ab * db;           // this half's two edges
+    contrib += __shfl_xor(contrib, 32);          // + the other half's
+    s_acc += contrib;
+    if (gl == 0) {  // stash d(alpha); fixed up below
+      if (va) d_logit[(long)ea * H + h] = da;
+      if (vb) d_logit[(long)eb * H + h] = db;
+    }
+  }
+  __threadfence_block();
+  for (int e = beg + lane; e < end; e += 64) {
+    const float da = d_logit[(long)e * H + h];
+    d_logit[(long)e * H + h] = alpha[(long)e * H + h] * (da - s_acc);
+  }
+}
+
 __global__ void attn_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ value,
                                 const int* __restrict__ row_ptr, const float* __restrict__ d_out,
                                 float* __restrict__ d_value, float* __restrict__ d_logit, const HeadTab T, float drop_p,
@@ -502,8 +593,12 @@ int eqf_attn_aggregate_fwd(const float* logit, const float* value, const int* ro
   // HBM-bound kernel: timed for the "HBM GB/s on the scatter" figure of bench.py (bytes are filled in there, the edge
   // count lives on the device)
   const int pid = eqf_prof_begin("attn_fwd", (hipStream_t)stream, 0.0, 0.0);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, logit, value, row_ptr, alpha, out,
-                     T, drop_p, seed);
+  if (T.G <= 32)
+    hipLaunchKernelGGL(attn_fwd_half_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, logit, value, row_ptr, alpha,
+                       out, T, drop_p, seed);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, logit, value, row_ptr, alpha, out,
+                       T, drop_p, seed);
   eqf_prof_end(pid, (hipStream_t)stream);
   EQF_CHECK_LAUNCH();
   return 0;
@@ -518,8 +613,12 @@ int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* ro
   if (err) return err;
   if (N <= 0) return 0;
   const int pid = eqf_prof_begin("attn_bwd", (hipStream_t)stream, 0.0, 0.0);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, alpha, value, row_ptr, d_out,
-                     d_value, d_logit, T, drop_p, seed);
+  if (T.G <= 32)
+    hipLaunchKernelGGL(attn_bwd_half_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, alpha, value, row_ptr, d_out,
+                       d_value, d_logit, T, drop_p, seed);
+  else
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, alpha, value, row_ptr, d_out,
+                       d_value, d_logit, T, drop_p, seed);
   eqf_prof_end(pid, (hipStream_t)stream);
   EQF_CHECK_LAUNCH();
   return 0;
