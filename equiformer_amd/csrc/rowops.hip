@@ -222,6 +222,72 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   d_in[idx] = v;
 }
 
+// Column-fixed variants: a thread owns ONE column and walks RB rows, so the 64-bit division idx / D, the segment search
+// and the `% mul` of the element-per-thread kernels above (~150 VALU instructions per element, paid on the same lanes
+// the fp32 MFMAs of concurrently running kernels would use) happen once per thread instead of once per element.
+__global__ __launch_bounds__(256) void gate_fwd_cols_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                            GateTab T, float c_silu, float c_sig, int RB) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= T.Dout) return;
+  int ia = c, ib = -1;
+  if (c >= T.S) {
+    int sg = 0;
+    while (sg + 1 < T.nseg && c >= T.out_off[sg + 1]) ++sg;
+    const int j = c - T.out_off[sg];
+    ia = T.in_off[sg] + j;
+    ib = T.goff[sg] + j % T.mul[sg];
+  }
+  const int r0 = blockIdx.y * RB, r1 = min(rows, r0 + RB);
+  const float* ir = in + (long)r0 * T.Din;
+  float* orow = out + (long)r0 * T.Dout + c;
+#pragma unroll 4
+  for (int r = r0; r < r1; ++r, ir += T.Din, orow += T.Dout) {
+    const float s = ir[ia];
+    *orow = (ib < 0) ? c_silu * s * sigmoidf_(s) : s * c_sig * sigmoidf_(ir[ib]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_cols_kernel(const float* __restrict__ in, const float* __restrict__ d_out,
+                                                            float* __restrict__ d_in, int rows, GateTab T, float c_silu,
+                                                            float c_sig, int RB) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per INPUT column
+  if (c >= T.Din) return;
+  int kind = 0, ia = c, ib = 0, mul = 0, d = 0;  // 0 scalar, 1 gate, 2 gated
+  if (c >= T.S && c < T.S + T.G) {
+    kind = 1;
+    int sg = 0;
+    while (sg + 1 < T.nseg && c >= T.goff[sg + 1]) ++sg;
+    const int u = c - T.goff[sg];
+    ia = T.out_off[sg] + u, ib = T.in_off[sg] + u, mul = T.mul[sg], d = T.d[sg];
+  } else if (c >= T.S + T.G) {
+    kind = 2;
+    int sg = 0;
+    while (sg + 1 < T.nseg && c >= T.in_off[sg + 1]) ++sg;
+    const int j = c - T.in_off[sg];
+    ia = T.out_off[sg] + j, ib = T.goff[sg] + j % T.mul[sg];
+  }
+  const int r0 = blockIdx.y * RB, r1 = min(rows, r0 + RB);
+  const float* ir = in + (long)r0 * T.Din;
+  const float* gr = d_out + (long)r0 * T.Dout;
+  float* drow = d_in + (long)r0 * T.Din + c;
+#pragma unroll 2
+  for (int r = r0; r < r1; ++r, ir += T.Din, gr += T.Dout, drow += T.Din) {
+    float v;
+    if (kind == 0) {
+      const float s = ir[c], sg = sigmoidf_(s);
+      v = gr[c] * c_silu * (sg + s * sg * (1.f - sg));
+    } else if (kind == 1) {
+      const float gsig = sigmoidf_(ir[c]);
+      float acc = 0.f;
+      for (int m = 0; m < d; ++m) acc += gr[ia + m * mul] * ir[ib + m * mul];
+      v = acc * c_sig * gsig * (1.f - gsig);
+    } else {
+      v = gr[ia] * c_sig * sigmoidf_(ir[ib]);
+    }
+    *drow = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- silu
 __global__ __launch_bounds__(256) void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n4,
                                                        long n, float c) {
@@ -476,9 +542,9 @@ int eqf_gate_fwd(const float* in, float* out, int rows, int S, const eqf_irreps*
   if (!in || !out || !gated) return EQF_E_BADARG;
   if (rows <= 0) return 0;
   const GateTab T = make_gatetab(S, *gated);
-  const long total = (long)rows * T.Dout;
-  hipLaunchKernelGGL(gate_fwd_kernel, dim3(eqf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, total, T,
-                     c_silu, c_sig);
+  const int RB = 8;
+  hipLaunchKernelGGL(gate_fwd_cols_kernel, dim3(eqf_cdiv(T.Dout, 256), eqf_cdiv(rows, RB)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, rows, T, c_silu, c_sig, RB);
   EQF_CHECK_LAUNCH();
   return 0;
 }
@@ -488,9 +554,9 @@ int eqf_gate_bwd(const float* in, const float* d_out, float* d_in, int rows, int
   if (!in || !d_out || !d_in || !gated) return EQF_E_BADARG;
   if (rows <= 0) return 0;
   const GateTab T = make_gatetab(S, *gated);
-  const long total = (long)rows * T.Din;
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(eqf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, d_out, d_in,
-                     total, T, c_silu, c_sig);
+  const int RB = 8;
+  hipLaunchKernelGGL(gate_bwd_cols_kernel, dim3(eqf_cdiv(T.Din, 256), eqf_cdiv(rows, RB)), dim3(256), 0,
+                     (hipStream_t)stream, in, d_out, d_in, rows, T, c_silu, c_sig, RB);
   EQF_CHECK_LAUNCH();
   return 0;
 }
