@@ -211,9 +211,10 @@ def main():
             extra["scatter"] = {"kernel": "attn_fwd (segment softmax + aggregation)", "bound": "hbm", "achieved": gbps,
                                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                                 "avg_launch_ms": sc["total_ms"] / sc["launches"], "algorithmic_bytes_per_launch": byts}
-        rad = [(n2, r2) for n2, r2 in prof.items() if n2.startswith("gemm_rows_128x128_mem")]
+        # the widest E-row GEMM with a memory A operand and an [N, K] weight = the radial MLP's last layer
+        rad = [(n2, r2) for n2, r2 in prof.items() if n2.startswith("gemm_rows_") and n2.endswith("_mem_nk")]
         if rad:
-            n2, r2 = max(rad, key=lambda kv: kv[1]["total_ms"])
+            n2, r2 = max(rad, key=lambda kv: kv[1]["flops"] / kv[1]["launches"])
             tf = r2["flops"] / r2["total_ms"] / 1e9
             extra["radial_mlp"] = {"kernel": n2 + " (radial MLP 64 -> 960)", "bound": "mfma", "achieved": tf,
                                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
