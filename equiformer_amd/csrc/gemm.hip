@@ -399,6 +399,8 @@ struct TnArgs {
   int rows_per_step;    // reduction rows staged per K step (<= BK)
   int steps_per_split;  // K steps handled by one blockIdx.z
   int vecA, vecB;
+  float* csA;  // optional: csA[m] += sum_rows A[row, m]  (bias gradient when A is dy), may be null
+  float* csB;  // optional: csB[n] += sum_rows B[row, n]  (bias gradient when B is dy), may be null
   DtpA dtp;
 };
 
@@ -410,6 +412,8 @@ struct TnP {  // one problem of a grouped launch (A operand from memory)
   int rows_per_step;
   int steps_per_split;
   int vecA, vecB;
+  float* csA;
+  float* csB;
 };
 struct TnGroup {
   int n;
@@ -447,6 +451,10 @@ __device__ __forceinline__ void gemm_tn_body(const ArgsT& g, const int bx, const
   LoaderNatural<BM, SA> la;
   LoaderDtp<TN_PAIRS> ld[SL];
   LoaderNatural<BN, SB> lb;
+  const bool do_csB = g.csB != nullptr && bx == 0;
+  const bool do_csA = AMODE == A_MEM && g.csA != nullptr && by == 0;
+  float cs = 0.f;
+  static_assert(BM + BN <= NTHREADS, "disjoint thread ranges for the two column sums");
 
   // in DTP mode the (tiny) coupling rows are read straight from global memory (L1 resident, lane-uniform)
   auto issue = [&](int s) {
@@ -489,9 +497,23 @@ __device__ __forceinline__ void gemm_tn_body(const ArgsT& g, const int bx, const
     lb.commit(Bs);
     __syncthreads();
     if (s + 1 < s_end) issue(s + 1);
+    // bias gradients ride along: the staged tiles already hold the rows whose column sums a separate colsum launch
+    // would re-read (rows past rcnt are zero in the tiles); one tile column per thread, first tile row / column only
+    if (do_csB && (int)threadIdx.x < BN) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) cs += Bs[k * SB + threadIdx.x];
+    } else if (do_csA && (int)threadIdx.x >= NTHREADS - BM) {
+      const int c = threadIdx.x - (NTHREADS - BM);
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) cs += As[k * SA + c];
+    }
     mma_step<TM, TN, SA, SB>(As, Bs, wm0, wn0, wk * (BK / WK), (wk + 1) * (BK / WK), acc);
     __syncthreads();
   }
+  if (do_csB && (int)threadIdx.x < BN && n0 + (int)threadIdx.x < g.N) atomicAdd(g.csB + n0 + threadIdx.x, cs);
+  if (do_csA && !(do_csB && (int)threadIdx.x < BN) && (int)threadIdx.x >= NTHREADS - BM &&
+      m0 + (int)threadIdx.x - (NTHREADS - BM) < g.M)
+    atomicAdd(g.csA + m0 + threadIdx.x - (NTHREADS - BM), cs);
 
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hi = lane >> 5;
@@ -706,8 +728,14 @@ int eqf_gemm_nt(const float* A, eqf_rows ra, const float* B, int ldb, float* C, 
 
 int eqf_gemm_tn(const float* A, eqf_rows ra, const float* B, eqf_rows rb, float* C, int ldc, int M, int N, int R,
                 void* stream) {
+  return eqf_gemm_tn_colsum(A, ra, B, rb, C, ldc, M, N, R, nullptr, nullptr, stream);
+}
+
+int eqf_gemm_tn_colsum(const float* A, eqf_rows ra, const float* B, eqf_rows rb, float* C, int ldc, int M, int N, int R,
+                       float* colsum_a, float* colsum_b, void* stream) {
   if (!A || !B || !C || ra.d < 1 || rb.d < 1) return EQF_E_BADARG;
   TnArgs a{};
+  a.csA = colsum_a, a.csB = colsum_b;
   a.A = {A, ra.d, ra.ld, ra.inner};
   a.B = {B, rb.d, rb.ld, rb.inner};
   a.C = C, a.ldc = ldc, a.M = M, a.N = N, a.R = R;
@@ -783,6 +811,8 @@ int eqf_gemm_group(const eqf_gemm_desc* d, int n, void* stream) {
       P.rows_per_step = BK;
       P.vecA = rows_vec_ok(d[i].A, d[i].ra);
       P.vecB = rows_vec_ok(d[i].B, d[i].rc);
+      P.csA = nullptr;
+      P.csB = const_cast<float*>(d[i].bias);  // kind 2: `bias` = accumulator of the column sums of B' (may be null)
       const int tiles = eqf_cdiv(P.M, 64) * eqf_cdiv(P.N, 64);
       const int total_steps = eqf_cdiv(P.R, BK);
       int ksplit = 1024 / (tiles > 0 ? tiles : 1);

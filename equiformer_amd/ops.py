@@ -215,16 +215,17 @@ def _lin_dgrad(dy, weight, spec):
     return dx
 
 
-def _lin_wgrad(x, dy, spec, dw):
-    """dw (flat, zero-initialised by the caller) += x^T dy per degree."""
+def _lin_wgrad(x, dy, spec, dw, db=None):
+    """dw (flat, zero-initialised by the caller) += x^T dy per degree; db (zero-initialised, optional) += the column
+    sums of the scalar block of dy, accumulated by the same launch while dy is staged."""
     n = x.shape[0]
     Din, Dout = spec.in_layout.dim, spec.out_layout.dim
     descs = []
     for (l, in_off, K, out_off, N, w_off) in spec.pairs:
         d = 2 * l + 1
         # kind 2: C[K,N] += sum_rows x[row, 0:K]^T dy[row, 0:N]; "rc" describes the dy rows, ldb = ldc
-        descs.append(_desc(2, (x, in_off), rows(d, Din, K), (dy, out_off), N, (dw, w_off), rows(d, Dout, N), None,
-                           K, N, n * d))
+        descs.append(_desc(2, (x, in_off), rows(d, Din, K), (dy, out_off), N, (dw, w_off), rows(d, Dout, N),
+                           db if l == 0 else None, K, N, n * d))
     _gemm_group(descs, _stream())
     return dw
 
@@ -313,12 +314,15 @@ class _IrrepsLinear(Function):
             dx = _lin_dgrad(dy, weight, spec)
         if ctx.needs_input_grad[1] or want_b:
             dw_, db_ = _zeros2(weight.numel(), spec.bias_dim if want_b else 0, x.device)
+        fused_b = want_b and ctx.needs_input_grad[1] and any(l == 0 and N == spec.bias_dim
+                                                              for (l, _, _, _, N, _) in spec.pairs)
         if ctx.needs_input_grad[1]:
-            dw = _lin_wgrad(x, dy, spec, dw_)
+            dw = _lin_wgrad(x, dy, spec, dw_, db_ if fused_b else None)
         if want_b:
             db = db_
-            j = spec.out_layout.seg_index(0)
-            call("eqf_colsum", _p(dy, spec.out_layout.offsets[j]), rows(1, Dout, 0), n, spec.bias_dim, _p(db), st)
+            if not fused_b:
+                j = spec.out_layout.seg_index(0)
+                call("eqf_colsum", _p(dy, spec.out_layout.offsets[j]), rows(1, Dout, 0), n, spec.bias_dim, _p(db), st)
         return dx, dw, db, None
 
 
@@ -342,11 +346,11 @@ def _dense_dgrad(dy, weight):
     return dx
 
 
-def _dense_wgrad(x, dy, dw):
-    """dw [N, K] (zero-initialised) += dy^T x"""
+def _dense_wgrad(x, dy, dw, db=None):
+    """dw [N, K] (zero-initialised) += dy^T x; db [N] (zero-initialised, optional) += column sums of dy (same launch)"""
     M, K = x.shape
     N = dy.shape[1]
-    call("eqf_gemm_tn", _p(dy), rows(1, N, 0), _p(x), rows(1, K, 0), _p(dw), K, N, K, M, _stream())
+    call("eqf_gemm_tn_colsum", _p(dy), rows(1, N, 0), _p(x), rows(1, K, 0), _p(dw), K, N, K, M, _p(db), None, _stream())
     return dw
 
 
@@ -421,10 +425,11 @@ class _DenseLinear(Function):
         if ctx.needs_input_grad[1] or want_b:
             dw_, db_ = _zeros2(weight.numel(), N if want_b else 0, x.device)
         if ctx.needs_input_grad[1]:
-            dw = _dense_wgrad(x, dy, dw_.view_as(weight))
+            dw = _dense_wgrad(x, dy, dw_.view_as(weight), db_ if want_b else None)
         if want_b:
             db = db_
-            call("eqf_colsum", _p(dy), rows(1, N, 0), M, N, _p(db), st)
+            if not ctx.needs_input_grad[1]:
+                call("eqf_colsum", _p(dy), rows(1, N, 0), M, N, _p(db), st)
         return dx, dw, db
 
 

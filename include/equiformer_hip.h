@@ -161,6 +161,13 @@ int eqf_gemm_nt(const float* A, eqf_rows ra, const float* B, int ldb, float* C, 
  * leading dimension ldc.  C is always ACCUMULATED into (split over row chunks with fp32 atomics). */
 int eqf_gemm_tn(const float* A, eqf_rows ra, const float* B, eqf_rows rb, float* C, int ldc, int M,
                 int N, int R, void* stream);
+/* eqf_gemm_tn that also accumulates the column sums of its operands while they are staged (the bias gradient of the
+ * same linear layer, otherwise a separate eqf_colsum pass over dy): colsum_a[m] += sum_rows A[row, m] and
+ * colsum_b[n] += sum_rows B[row, n]; either may be NULL.  In eqf_gemm_group a kind-2 descriptor's `bias` field is the
+ * colsum_b accumulator.  [ref: the `.bias` gradients of nn.Linear (radial_func.py) and of LinearRS,
+ * nets/tensor_product_rescale.py:93-110] */
+int eqf_gemm_tn_colsum(const float* A, eqf_rows ra, const float* B, eqf_rows rb, float* C, int ldc, int M, int N,
+                       int R, float* colsum_a, float* colsum_b, void* stream);
 
 /* Several independent GEMMs in ONE launch per kind (the per-degree GEMMs of one irreps linear; the node-level linears
  * have only N ~ 2 k rows and are launch / latency bound).  n <= 4 problems.
