@@ -37,6 +37,7 @@ unsigned long long* g_sfc_dbg = nullptr;  // set by eqf_sfc_debug_buffer (develo
 // 8-12 % faster for bwd_weight, 0-6 % for bwd_data, and 0-14 % SLOWER for fwd (its workgroups of one degree share the
 // staged weight slabs, which the degree-major order keeps hot).  eqf_sfc_debug_order overrides all three for A/B runs.
 int g_sfc_order[3] = {0, 1, 1};
+bool g_sfc_x6_default = true;  // forward matrix step: split-precision bf16 x 6 (true) or exact-fp32 MFMA (false)
 int g_sfc_exp = 0;  // development aid (eqf_sfc_debug_exp): bit mask that switches phases of the kernels OFF to time the rest
 
 constexpr int SFC_MAX_DEG = 4;
@@ -174,15 +175,65 @@ __device__ __forceinline__ void f_mma(const int (&aidx)[FT], const int (&bidx)[F
   }
 }
 
+// ---- split-precision matrix step (X6): fp32 operands, bf16 matrix cores ------------------------------------------
+// The fp32 MFMA runs on the VALU's FMA lanes, so it cannot overlap with the generation / addressing
+// work of the same kernel.  Here every fp32 operand value is split exactly into three bf16 terms x = x1 + x2 + x3
+// (v_cvt_pk_bf16_f32, two subtractions) and a . b is evaluated as the six products a1b1, a1b2, a2b1, a1b3, a3b1, a2b2
+// on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation): error 3-4e-7 of the result scale, the same
+// as the fp32 GEMM (tools/bf16_split_error.py), at 12 x 32 cycles per 32 x 32 x 32 tile instead of 16 x 64 -- and on a
+// pipe of its own.  The A tile is then kept row-major in LDS ([row][k], stride X6_SA floats) so that a lane's eight
+// consecutive k values are two 16-byte reads.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int X6_SA = 36;  // floats per A row: 32 k + 4 pad (16-byte aligned rows, staggered banks)
+
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    const float r1 = v[j] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    p1[j] = h, p2[j] = m, p3[j] = (__bf16)r2;
+  }
+}
+
+template <int D3, int NT, int FT>
+__device__ __forceinline__ void f_mma6(const int (&arow)[FT], const int (&bcol)[FT], f32x16 (&acc)[FT]) {
+  constexpr int F_SB = f_sb(D3, FT);
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg) {  // two groups of 16 k per 32-channel slab
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      float av[8], bw[8];
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg + 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[j] = a0[j], av[4 + j] = a1[j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bw[j] = sfc_lds[bcol[i] + (16 * kg + j) * F_SB];
+      bf16x8 x1, x2, x3, y1, y2, y3;
+      split3(av, x1, x2, x3);
+      split3(bw, y1, y2, y3);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, y2, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, y3, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, y1, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, y2, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, y1, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, y1, acc[i], 0, 0, 0);
+    }
+  }
+}
+
 // PAIR: the workgroup has 512 threads = two independent 256-thread groups working on neighbouring edge tiles with
 // their own LDS partitions, run in ANTI-PHASE through the shared barriers: while one group's waves issue the MFMAs of
 // slab s, the other group's waves (the co-resident wave of every SIMD) wait for loads, generate the next A tile on the
 // VALU and write LDS.  Two free-running 256-thread workgroups per CU do the same work with the same resources, but
 // measured additively (MFMA 120 us + loads 45 + generation 30 + fixed 66 of 246 us: tools/sfc_exp.py): nothing forces
 // their matrix-pipe and memory phases apart.
-template <int D3, int MAXD, bool PAIR>
+template <int D3, int MAXD, bool PAIR, bool X6>
 __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const int b) {
   constexpr int ROWS = F_TE * D3, RT = ROWS / 32, SA = ROWS + 1;
+  constexpr int A_FLOATS = X6 ? ROWS * X6_SA : 32 * SA;  // A tile: [row][k] (X6) or [k][row]
   constexpr int FT = (MAXD <= 5) ? 3 : F_MAXT;  // accumulator tiles per wave (host: `ft`)
   constexpr int CTCAP = f_ctcap(D3, FT), F_SB = f_sb(D3, FT);
   const SfcDeg& D = g.c.deg[di];
@@ -197,7 +248,7 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
   const int ncols = min(g.cps[di], D.Ncat - ncol0);
   const int CT = ncols >> 5;
   // LDS partition of this group (float offsets into sfc_lds)
-  const int AS0 = grp * g.grp_floats, BS0 = AS0 + 32 * SA, MT0 = BS0 + 32 * F_SB;
+  const int AS0 = grp * g.grp_floats, BS0 = AS0 + A_FLOATS, MT0 = BS0 + 32 * F_SB;
   const int m_len = D.m_len;
 
   const int t = PAIR ? ((int)threadIdx.x & 255) : (int)threadIdx.x;
@@ -218,8 +269,13 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     const int ct = tt / RT, rt = tt - ct * RT;
     aoff[i] = rt * 32;
     boff[i] = ct * 32;
-    aidx[i] = AS0 + hi * SA + r + aoff[i];
-    bidx[i] = BS0 + hi * F_SB + r + boff[i];
+    if (X6) {  // lane = (row r of the tile, k half hi): eight consecutive k of its row / its column
+      aidx[i] = AS0 + (aoff[i] + r) * X6_SA + 8 * hi;
+      bidx[i] = BS0 + (8 * hi) * F_SB + boff[i] + r;
+    } else {
+      aidx[i] = AS0 + hi * SA + r + aoff[i];
+      bidx[i] = BS0 + hi * F_SB + r + boff[i];
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
   }
@@ -294,8 +350,12 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
 #pragma unroll
         for (int i = 0; i < D1; ++i) a += xv[q][i] * sfc_lds[mp + i * D3 + m3];
         a *= wm;
+        if (X6) {
+          *reinterpret_cast<f32x4*>(&sfc_lds[AS0 + (m3 * F_TE + eg + 32 * q) * X6_SA + 4 * c4]) = a;
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) sfc_lds[awb + c * SA + 32 * q + m3 * F_TE] = a[c];
+          for (int c = 0; c < 4; ++c) sfc_lds[awb + c * SA + 32 * q + m3 * F_TE] = a[c];
+        }
       }
     }
   };
@@ -353,13 +413,26 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     tick(2);  // barrier
     if (s + 1 < nslab && !(g.exp & 4)) issue(s + 1);
     tick(3);  // issue of the next slab's loads
-    if (!(g.exp & 1)) switch (NT) {
-      case 1: f_mma<D3, 1, FT>(aidx, bidx, acc); break;
-      case 2: f_mma<D3, 2, FT>(aidx, bidx, acc); break;
-      case 3: f_mma<D3, 3, FT>(aidx, bidx, acc); break;
-      default:
-        if constexpr (FT >= 4) f_mma<D3, 4, FT>(aidx, bidx, acc);
-        break;
+    if (!(g.exp & 1)) {
+      if constexpr (X6) {
+        switch (NT) {
+          case 1: f_mma6<D3, 1, FT>(aidx, bidx, acc); break;
+          case 2: f_mma6<D3, 2, FT>(aidx, bidx, acc); break;
+          case 3: f_mma6<D3, 3, FT>(aidx, bidx, acc); break;
+          default:
+            if constexpr (FT >= 4) f_mma6<D3, 4, FT>(aidx, bidx, acc);
+            break;
+        }
+      } else {
+        switch (NT) {
+          case 1: f_mma<D3, 1, FT>(aidx, bidx, acc); break;
+          case 2: f_mma<D3, 2, FT>(aidx, bidx, acc); break;
+          case 3: f_mma<D3, 3, FT>(aidx, bidx, acc); break;
+          default:
+            if constexpr (FT >= 4) f_mma<D3, 4, FT>(aidx, bidx, acc);
+            break;
+        }
+      }
     }
     tick(4);  // MFMA loop
     __syncthreads();
@@ -394,18 +467,18 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
   if (PAIR && grp == 0) __syncthreads();  // the barrier that ends group 1's last MFMA phase
 }
 
-template <int MAXD, bool PAIR>
+template <int MAXD, bool PAIR, bool X6 = false>
 __global__ __launch_bounds__((PAIR ? 512 : 256), (PAIR || MAXD > 5 ? 1 : 2)) void sfc_fwd_kernel(const SfcFwdArgs g) {
   int tile, y;
   if (!order_xy(g.ord, blockIdx.x, tile, y)) return;
   const int di = g.y_deg[y];
   const int b = tile * g.nsplit[di] + g.y_split[y];
   switch (g.c.deg[di].d3) {
-    case 1: f_block<1, MAXD, PAIR>(g, di, b); break;
-    case 3: f_block<3, MAXD, PAIR>(g, di, b); break;
-    case 5: f_block<5, MAXD, PAIR>(g, di, b); break;
+    case 1: f_block<1, MAXD, PAIR, X6>(g, di, b); break;
+    case 3: f_block<3, MAXD, PAIR, X6>(g, di, b); break;
+    case 5: f_block<5, MAXD, PAIR, X6>(g, di, b); break;
     default:
-      if constexpr (MAXD >= 7) f_block<7, MAXD, PAIR>(g, di, b);
+      if constexpr (MAXD >= 7) f_block<7, MAXD, PAIR, X6>(g, di, b);
       break;
   }
 }
@@ -1095,6 +1168,9 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
   for (int d = 0; d < A.c.ndeg; ++d) md = A.c.deg[d].d3 > md ? A.c.deg[d].d3 : md;
   const int ft = md <= 5 ? 3 : F_MAXT;
   const int ntile = eqf_cdiv(E, F_TE);
+  // matrix step: 1 = split-precision bf16 x 6 on the matrix cores (f_mma6), 0 = exact-fp32 MFMA (development switch
+  // 64 of eqf_sfc_debug_exp selects the other one for A/B runs)
+  const bool x6 = md <= 5 && ((g_sfc_exp & 64) ? !g_sfc_x6_default : g_sfc_x6_default);
   size_t lds = 0;
   int ny = 0;
   for (int d = 0; d < A.c.ndeg; ++d) {
@@ -1112,14 +1188,15 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
       A.y_deg[ny] = (signed char)d, A.y_split[ny] = (signed char)k;
       ++ny;
     }
-    const size_t need = sizeof(float) * (32 * (F_TE * D.d3 + 1) + 32 * f_sb(D.d3, ft) + (size_t)F_TE * D.m_len);
+    const size_t a_floats = x6 ? (size_t)F_TE * D.d3 * X6_SA : (size_t)32 * (F_TE * D.d3 + 1);
+    const size_t need = sizeof(float) * (a_floats + 32 * f_sb(D.d3, ft) + (size_t)F_TE * D.m_len);
     if (need > lds) lds = need;
   }
   if (lds > SFC_LDS_LIMIT) return EQF_E_UNSUPPORTED;
   lds = (lds + 15) & ~(size_t)15;
   // paired workgroups measured SLOWER than free-running ones (sep_act 297 vs 230 us, tools/sfc_exp.py): kept behind the
   // development switch only
-  const bool pair = md <= 5 && 2 * lds <= SFC_LDS_LIMIT && (g_sfc_exp & 16);
+  const bool pair = md <= 5 && !x6 && 2 * lds <= SFC_LDS_LIMIT && (g_sfc_exp & 16);
   A.grp_floats = (int)(lds / sizeof(float));
   int blk = 0;
   A.ord = make_order(0, pair ? eqf_cdiv(ntile, 2) : ntile, ny, blk);
@@ -1131,9 +1208,12 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
     hipFuncSetAttribute((const void*)sfc_fwd_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
     hipFuncSetAttribute((const void*)sfc_fwd_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
     hipFuncSetAttribute((const void*)sfc_fwd_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
+    hipFuncSetAttribute((const void*)sfc_fwd_kernel<5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        SFC_LDS_LIMIT);
     attr_set = true;
   }
-  if (pair) hipLaunchKernelGGL((sfc_fwd_kernel<5, true>), dim3(blk), dim3(512), 2 * lds, st, A);
+  if (x6 && !pair) hipLaunchKernelGGL((sfc_fwd_kernel<5, false, true>), dim3(blk), dim3(256), lds, st, A);
+  else if (pair) hipLaunchKernelGGL((sfc_fwd_kernel<5, true>), dim3(blk), dim3(512), 2 * lds, st, A);
   else if (md <= 5)
     hipLaunchKernelGGL((sfc_fwd_kernel<5, false>), dim3(blk), dim3(256), (g_sfc_exp & 32) ? (size_t)100 * 1024 : lds, st, A);
   else hipLaunchKernelGGL((sfc_fwd_kernel<7, false>), dim3(blk), dim3(256), lds, st, A);

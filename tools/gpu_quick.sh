@@ -1,2 +1,3 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_model.py -m gpu -x -q -s -k "qm9_forward_backward" 2>&1 | tail -5
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2z; export TMPDIR=/tmp
+timeout 200 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "sfc or separable" 2>&1 | tail -4
+timeout 100 python tools/sfc_exp.py 2>&1 | grep "fwd exp" | tee gpurun_out/r2z/x6.txt

@@ -53,10 +53,10 @@ def run(name, irr, sh_irr, out_irr, n2, use_w):
     b = lambda: call("eqf_sfc_bwd_data", P(x), P(M), P(w), table.c_ref, Wl, P(weight2), P(d1), lay.c_ref, P(d2), n2,
                      P(dx), P(dw), None, E, st())
     L = _lib.load()
-    for mask in (0, 32, 1, 33):
+    for mask in (0, 64, 1, 65, 2, 66):
         L.eqf_sfc_debug_exp(mask)
         print("%-10s fwd exp=%2d  %8.1f us" % (name, mask, timeit(f)), flush=True)
-    for mask in (0, 32, 1, 33):
+    for mask in (0,):
         L.eqf_sfc_debug_exp(mask)
         print("%-10s bwd exp=%2d  %8.1f us" % (name, mask, timeit(b)), flush=True)
     L.eqf_sfc_debug_exp(0)
