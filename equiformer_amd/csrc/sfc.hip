@@ -200,20 +200,35 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& p1, bf16x8& 
 template <int D3, int NT, int FT>
 __device__ __forceinline__ void f_mma6(const int (&arow)[FT], const int (&bcol)[FT], f32x16 (&acc)[FT]) {
   constexpr int F_SB = f_sb(D3, FT);
+  // consecutive tiles of a wave often share their row tile (degree 0: two row tiles, many column tiles) or their
+  // column tile (degree 2: one column tile): the split fragments of the shared operand are then reused -- the split is
+  // the VALU cost of this step (44 instructions per fragment).  The flags are wave-uniform.
+  bool same_a[NT], same_b[NT];
+  same_a[0] = same_b[0] = false;
+#pragma unroll
+  for (int i = 1; i < NT; ++i) {
+    same_a[i] = __builtin_amdgcn_readfirstlane((int)(arow[i] == arow[i - 1])) != 0;
+    same_b[i] = __builtin_amdgcn_readfirstlane((int)(bcol[i] == bcol[i - 1])) != 0;
+  }
 #pragma unroll
   for (int kg = 0; kg < 2; ++kg) {  // two groups of 16 k per 32-channel slab
+    bf16x8 x1, x2, x3, y1, y2, y3;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      float av[8], bw[8];
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg]);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg + 4]);
+      if (!same_a[i]) {
+        float av[8];
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg]);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg + 4]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) av[j] = a0[j], av[4 + j] = a1[j];
+        for (int j = 0; j < 4; ++j) av[j] = a0[j], av[4 + j] = a1[j];
+        split3(av, x1, x2, x3);
+      }
+      if (!same_b[i]) {
+        float bw[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bw[j] = sfc_lds[bcol[i] + (16 * kg + j) * F_SB];
-      bf16x8 x1, x2, x3, y1, y2, y3;
-      split3(av, x1, x2, x3);
-      split3(bw, y1, y2, y3);
+        for (int j = 0; j < 8; ++j) bw[j] = sfc_lds[bcol[i] + (16 * kg + j) * F_SB];
+        split3(bw, y1, y2, y3);
+      }
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, y2, acc[i], 0, 0, 0);
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, y3, acc[i], 0, 0, 0);
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, y1, acc[i], 0, 0, 0);
