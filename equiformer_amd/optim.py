@@ -53,9 +53,7 @@ class FlatAdamW(torch.optim.Optimizer):
         ps = [p for g in self.param_groups for p in g["params"]]
         if not ps:
             raise ValueError("FlatAdamW got no parameters")
-        if any((not p.is_cuda) or p.dtype != torch.float32 for p in ps):
-            from .ops import HipOnlyError
-            raise HipOnlyError("FlatAdamW runs on GPU fp32 parameters only")
+        self._check_params(ps)
         if reducer is not None:
             if [id(p) for p in reducer.params] != [id(p) for p in self._ordered(ps, reducer.params)]:
                 raise ValueError("reducer and optimizer must hold the same parameters")
@@ -89,6 +87,12 @@ class FlatAdamW(torch.optim.Optimizer):
         if ema_decay is not None:
             self.flat_ema = self.flat_p.clone()
         self._step = 0
+
+    @staticmethod
+    def _check_params(ps):
+        if any((not p.is_cuda) or p.dtype != torch.float32 for p in ps):
+            from .ops import HipOnlyError
+            raise HipOnlyError("FlatAdamW runs on GPU fp32 parameters only")
 
     @staticmethod
     def _ordered(ps, like):
@@ -145,6 +149,38 @@ class FlatAdamW(torch.optim.Optimizer):
         for p in self._params:
             self.state[p]["step"] = self._step
         return loss
+
+    def load_state_dict(self, state_dict):
+        """Restores lr / betas / eps / weight decay of the groups and copies exp_avg / exp_avg_sq / step INTO the flat
+        buffers (the per-parameter state tensors stay views of them)."""
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        for g, sg in zip(self.param_groups, groups):
+            if len(g["params"]) != len(sg["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of the group")
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in sg:
+                    g[k] = tuple(sg[k]) if k == "betas" else sg[k]
+        order = [p for g in self.param_groups for p in g["params"]]
+        ids = [i for sg in groups for i in sg["params"]]
+        step = 0
+        with torch.no_grad():
+            for p, i in zip(order, ids):
+                st = state_dict["state"].get(i)
+                if st is None:
+                    continue
+                self.state[p]["exp_avg"].copy_(st["exp_avg"])
+                self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
+                step = max(step, int(st["step"]))
+            wd_of = {id(p): g["weight_decay"] for g in self.param_groups for p in g["params"]}
+            off = 0
+            for p, k in zip(self._params, self.sizes):
+                self.flat_wd[off:off + k].fill_(float(wd_of[id(p)]))
+                off += k
+        self._step = step
+        for p in self._params:
+            self.state[p]["step"] = step
 
     def grad_norm(self):
         """Global gradient norm of the last clipped step (device scalar, no sync)."""

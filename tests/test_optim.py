@@ -69,6 +69,48 @@ def test_add_weight_decay_name_rules():
     assert nd["weight_decay"] == 0.0 and d["weight_decay"] == 0.01
 
 
+def test_flat_adamw_state_dict_round_trip_keeps_flat_aliasing():
+    """Host logic only (no step): parameters / moments alias the flat buffers, state_dict has torch.optim.AdamW's
+    layout, load_state_dict copies INTO the flat buffers."""
+    from equiformer_amd.optim import FlatAdamW
+
+    class HostOnly(FlatAdamW):  # the GPU-only guard is the single thing a CPU test has to bypass
+        @staticmethod
+        def _check_params(ps):
+            pass
+
+    def make(seed):
+        g = torch.Generator().manual_seed(seed)
+        ps = [torch.nn.Parameter(torch.randn(3, 4, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g)),
+              torch.nn.Parameter(torch.randn(2, 2, generator=g))]
+        return ps, HostOnly([{"params": ps[:1], "weight_decay": 0.0}, {"params": ps[1:], "weight_decay": 0.01}],
+                            lr=1e-3, ema_decay=0.9)
+
+    ps, a = make(0)
+    before = [p.detach().clone() for p in ps]
+    assert all(p.data_ptr() >= a.flat_p.data_ptr() and p.data_ptr() < a.flat_p.data_ptr() + 4 * a.n for p in ps)
+    assert all(torch.equal(p.detach(), b) for p, b in zip(ps, before))
+    assert torch.equal(a.flat_wd, torch.tensor([0.0] * 12 + [0.01] * 9))
+    a.flat_m.copy_(torch.arange(a.n, dtype=torch.float32))
+    a.flat_v.copy_(torch.arange(a.n, dtype=torch.float32) * 2)
+    a._step = 7
+    for p in ps:
+        a.state[p]["step"] = 7
+    sd = a.state_dict()
+    assert sd["state"][1]["exp_avg"].tolist() == list(range(12, 17)) and sd["state"][2]["step"] == 7
+    assert [len(g["params"]) for g in sd["param_groups"]] == [1, 2]
+    ps2, b = make(1)
+    sd["param_groups"][0]["lr"] = sd["param_groups"][1]["lr"] = 5e-4
+    b.load_state_dict(sd)
+    assert torch.equal(b.flat_m, a.flat_m) and torch.equal(b.flat_v, a.flat_v) and b._step == 7
+    assert b.param_groups[0]["lr"] == 5e-4 and b.state[ps2[2]]["step"] == 7
+    m = b.state[ps2[1]]["exp_avg"]
+    assert m.data_ptr() == b.flat_m.data_ptr() + 4 * 12  # still a view of the flat buffer
+    em = b.ema_module(torch.nn.ParameterList(ps2))
+    assert all(not q.requires_grad for q in em.parameters())
+    assert next(iter(em.parameters())).data_ptr() == b.flat_ema.data_ptr()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("clip,ema", [(None, None), (1.5, 0.99)])
 def test_flat_adamw_matches_oracle(clip, ema):
