@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 // the fp32 MFMAs of concurrently running kernels would use) happen once per thread instead of once per element.
 __global__ __launch_bounds__(256) void gate_fwd_cols_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
                                                             GateTab T, float c_silu, float c_sig, int RB) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;  // row blocks run along grid.x (no 65 535 limit)
   if (c >= T.Dout) return;
   int ia = c, ib = -1;
   if (c >= T.S) {
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void gate_fwd_cols_kernel(const float* __restr
     ia = T.in_off[sg] + j;
     ib = T.goff[sg] + j % T.mul[sg];
   }
-  const int r0 = blockIdx.y * RB, r1 = min(rows, r0 + RB);
+  const int r0 = blockIdx.x * RB, r1 = min(rows, r0 + RB);
   const float* ir = in + (long)r0 * T.Din;
   float* orow = out + (long)r0 * T.Dout + c;
 #pragma unroll 4
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void gate_fwd_cols_kernel(const float* __restr
 __global__ __launch_bounds__(256) void gate_bwd_cols_kernel(const float* __restrict__ in, const float* __restrict__ d_out,
                                                             float* __restrict__ d_in, int rows, GateTab T, float c_silu,
                                                             float c_sig, int RB) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per INPUT column
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;  // one thread per INPUT column; row blocks along grid.x
   if (c >= T.Din) return;
   int kind = 0, ia = c, ib = 0, mul = 0, d = 0;  // 0 scalar, 1 gate, 2 gated
   if (c >= T.S && c < T.S + T.G) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void gate_bwd_cols_kernel(const float* __restr
     const int j = c - T.in_off[sg];
     ia = T.out_off[sg] + j, ib = T.goff[sg] + j % T.mul[sg];
   }
-  const int r0 = blockIdx.y * RB, r1 = min(rows, r0 + RB);
+  const int r0 = blockIdx.x * RB, r1 = min(rows, r0 + RB);
   const float* ir = in + (long)r0 * T.Din;
   const float* gr = d_out + (long)r0 * T.Dout;
   float* drow = d_in + (long)r0 * T.Din + c;
@@ -543,7 +543,7 @@ int eqf_gate_fwd(const float* in, float* out, int rows, int S, const eqf_irreps*
   if (rows <= 0) return 0;
   const GateTab T = make_gatetab(S, *gated);
   const int RB = 8;
-  hipLaunchKernelGGL(gate_fwd_cols_kernel, dim3(eqf_cdiv(T.Dout, 256), eqf_cdiv(rows, RB)), dim3(256), 0,
+  hipLaunchKernelGGL(gate_fwd_cols_kernel, dim3(eqf_cdiv(rows, RB), eqf_cdiv(T.Dout, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, out, rows, T, c_silu, c_sig, RB);
   EQF_CHECK_LAUNCH();
   return 0;
@@ -555,7 +555,7 @@ int eqf_gate_bwd(const float* in, const float* d_out, float* d_in, int rows, int
   if (rows <= 0) return 0;
   const GateTab T = make_gatetab(S, *gated);
   const int RB = 8;
-  hipLaunchKernelGGL(gate_bwd_cols_kernel, dim3(eqf_cdiv(T.Din, 256), eqf_cdiv(rows, RB)), dim3(256), 0,
+  hipLaunchKernelGGL(gate_bwd_cols_kernel, dim3(eqf_cdiv(rows, RB), eqf_cdiv(T.Din, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, d_out, d_in, rows, T, c_silu, c_sig, RB);
   EQF_CHECK_LAUNCH();
   return 0;
