@@ -999,7 +999,9 @@ class SfcSpec:
         # LDS footprint of the forward workgroup (A tile + weight tile + coupling tile of 64 edges), see sfc.hip
         for (l3, _, _, _) in self.degs:
             m_len = sum((2 * p["l1"] + 1) * (2 * l3 + 1) for p in table.paths if p["l3"] == l3)
-            ok = ok and 4 * (32 * (64 * (2 * l3 + 1) + 1) + 32 * 68 + 64 * m_len) <= 160 * 1024
+            rows = 64 * (2 * l3 + 1)
+            a_floats = max(32 * (rows + 1), rows * 36)  # [k][row] (fp32 MFMA step) / [row][k] (split-precision step)
+            ok = ok and 4 * (a_floats + 32 * 68 + 64 * m_len) <= 160 * 1024
         self.supported = ok and len(self.degs) <= 4
         self.weight_numel = sum(k * n for (_, k, n, _) in self.degs)
         k0 = [k for (l3, k, _, _) in self.degs if l3 == 0]
