@@ -101,5 +101,27 @@ def main():
           dict(energy=e.detach().numpy()))
 
 
+def make_linear():
+    """QM9-shaped, linear-message attention (nonlinear_message=False, reference :459-465,497-502); generated separately
+    so that the older fixtures are not rewritten."""
+    kw = dict(SMALL_L2, nonlinear_message=False)
+    m = onets.GraphAttentionTransformer(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **kw).eval()
+    fill_deterministic(m, 14)
+    d = qm9_like_batch(3, 12, side=5.5, seed=8)
+    md = m.double()
+    y = md(None, d["pos"].double(), d["batch"], d["z"])
+    loss = (y.squeeze() - d["y"].double()).abs().mean()
+    grads = torch.autograd.grad(loss, [md.blocks[0].ga.sep.lin.tp.weight, md.blocks[1].ga.alpha_dot,
+                                       md.blocks[0].ga.sep.lin.bias[0]])
+    _save("qm9_small_linear", m.float(), dict(pos=d["pos"].numpy(), z=d["z"].numpy(), batch=d["batch"].numpy(),
+                                             y=d["y"].numpy()),
+          dict(energy=y.detach().numpy(), loss=loss.item(), g_sep_lin=grads[0].numpy(), g_alpha_dot=grads[1].numpy(),
+               g_sep_bias=grads[2].numpy()))
+
+
 if __name__ == "__main__":
-    main()
+    if "--linear" in sys.argv:
+        make_linear()
+    else:
+        main()
+        make_linear()

@@ -54,6 +54,19 @@ def test_oracle_reproduces_qm9_fixture():
     assert _rel(y32, outs["energy"]) < TOL
 
 
+def test_oracle_reproduces_linear_message_fixture():
+    from oracle import nets as onets
+    ins, outs = _load("qm9_small_linear")
+    m = fill_deterministic(onets.GraphAttentionTransformer(irreps_in="5x0e", max_radius=5.0, number_of_basis=32,
+                                                           **dict(mg.SMALL_L2, nonlinear_message=False)).eval(), 14)
+    pos, z, batch = torch.as_tensor(ins["pos"]), torch.as_tensor(ins["z"]), torch.as_tensor(ins["batch"])
+    y64 = m.double()(None, pos.double(), batch, z)
+    assert _rel(y64, outs["energy"]) < 1e-10
+    loss = (y64.squeeze() - torch.as_tensor(ins["y"]).double()).abs().mean()
+    g = torch.autograd.grad(loss, [m.blocks[0].ga.sep.lin.tp.weight, m.blocks[0].ga.sep.lin.bias[0]])
+    assert _rel(g[0], outs["g_sep_lin"]) < 1e-9 and _rel(g[1], outs["g_sep_bias"]) < 1e-9
+
+
 @pytest.mark.parametrize("tag,kw", [("md17_small_l2", mg.SMALL_L2), ("md17_small_l3", mg.SMALL_L3)])
 def test_oracle_reproduces_md17_fixture(tag, kw):
     from oracle import nets as onets
@@ -97,6 +110,22 @@ def test_hip_reproduces_qm9_fixture():
                                    m.blocks[0].ga.sep_act.dtp_rad.net[0].weight, m.rbf.mean])
     for got, key in zip(g, ("g_sep_act_lin", "g_alpha_dot", "g_rad0", "g_rbf_mean")):
         assert _rel(got, outs[key]) < 5e-4, key  # gradients: looser (sums of many fp32 terms), still fp32-class
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_linear_message_fixture():
+    dev = torch.device("cuda:0")
+    ins, outs = _load("qm9_small_linear")
+    m = _hip_model("GraphAttentionTransformer", "graph_attention_transformer", 14, irreps_in="5x0e", max_radius=5.0,
+                   number_of_basis=32, **dict(mg.SMALL_L2, nonlinear_message=False))
+    pos, z, batch = (torch.as_tensor(ins[k]).to(dev) for k in ("pos", "z", "batch"))
+    y = m(None, pos, batch, z)
+    assert _rel(y, outs["energy"]) < TOL
+    loss = (y.squeeze() - torch.as_tensor(ins["y"]).to(dev)).abs().mean()
+    g = torch.autograd.grad(loss, [m.blocks[0].ga.sep.lin.tp.weight, m.blocks[1].ga.alpha_dot,
+                                   m.blocks[0].ga.sep.lin.bias[0]])
+    for got, key in zip(g, ("g_sep_lin", "g_alpha_dot", "g_sep_bias")):
+        assert _rel(got, outs[key]) < 5e-4, key
 
 
 @pytest.mark.gpu
