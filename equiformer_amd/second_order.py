@@ -36,38 +36,72 @@ def vjp(fn, inputs, grad_outputs):
 
 
 # ------------------------------------------------------------------------------------------------- row-local ops
+# The second-order step is bound by the number of launches (every tensor op here turns into three or more kernels
+# once it has been differentiated twice), so the per-segment loops of the reference are folded into a few products
+# with small constant 0/1 matrices that are built once per (layout, device, dtype).
+_consts = {}
+
+
+def _ln_consts(layout, device, dtype):
+    key = ("ln", layout.irreps.__repr__(), str(device), dtype)
+    c = _consts.get(key)
+    if c is None:
+        D, nseg = layout.dim, len(layout.segs)
+        P = torch.eye(D, dtype=dtype)                       # subtracts the channel mean on the l = 0 segments
+        A = torch.zeros(D, nseg, dtype=dtype)               # column -> segment, weighted 1 / (mul (2l+1))
+        nw = sum(m for m, _ in layout.segs)
+        Cw = torch.zeros(nw, D, dtype=dtype)                # affine_weight index -> columns
+        nb = sum(m for m, l in layout.segs if l == 0)
+        Cb = torch.zeros(max(nb, 1), D, dtype=dtype)        # affine_bias index -> columns
+        iw = ib = 0
+        for s, ((mul, l), off) in enumerate(zip(layout.segs, layout.offsets)):
+            d = 2 * l + 1
+            if l == 0:
+                P[off:off + mul, off:off + mul] -= 1.0 / mul
+                Cb[torch.arange(ib, ib + mul), torch.arange(off, off + mul)] = 1.0
+                ib += mul
+            A[off:off + mul * d, s] = 1.0 / (mul * d)
+            for m in range(d):
+                Cw[torch.arange(iw, iw + mul), torch.arange(off + m * mul, off + (m + 1) * mul)] = 1.0
+            iw += mul
+        c = tuple(t.to(device) for t in (P, A, (A > 0).to(dtype).t().contiguous(), Cw, Cb))
+        _consts[key] = c
+    return c
+
+
 def layer_norm(x, weight, bias, layout, eps):
     """EquivariantLayerNormV2, 'component' normalisation [ref: nets/layer_norm.py:89-152]; rows in CF layout."""
-    outs, iw, ib = [], 0, 0
-    for (mul, l), off in zip(layout.segs, layout.offsets):
-        d = 2 * l + 1
-        f = x[:, off:off + mul * d].reshape(-1, d, mul)
-        if l == 0:
-            f = f - f.mean(dim=2, keepdim=True)
-        nrm = f.pow(2).mean(dim=1).mean(dim=1, keepdim=True)
-        nrm = (nrm + eps).pow(-0.5) * weight[None, iw:iw + mul]
-        iw += mul
-        f = f * nrm[:, None, :]
-        if l == 0:
-            f = f + bias[ib:ib + mul][None, None, :]
-            ib += mul
-        outs.append(f.reshape(-1, mul * d))
-    return torch.cat(outs, dim=1)
+    P, A, B, Cw, Cb = _ln_consts(layout, x.device, x.dtype)
+    xc = x @ P                                               # l = 0: minus the mean over channels
+    rs = ((xc * xc) @ A + eps).pow(-0.5)                     # [n, segments]: 1 / sqrt(mean over (m, channel) + eps)
+    y = xc * (rs @ B) * (weight @ Cw)
+    if bias.numel():
+        y = y + bias @ Cb
+    return y
+
+
+def _gate_consts(S, gated_layout, device, dtype):
+    key = ("gate", S, gated_layout.irreps.__repr__(), str(device), dtype)
+    c = _consts.get(key)
+    if c is None:
+        G = sum(m for m, _ in gated_layout.segs)
+        Bg = torch.zeros(G, gated_layout.dim, dtype=dtype)   # gate index -> the columns it multiplies
+        ig = 0
+        for (mul, l), off in zip(gated_layout.segs, gated_layout.offsets):
+            for m in range(2 * l + 1):
+                Bg[torch.arange(ig, ig + mul), torch.arange(off + m * mul, off + (m + 1) * mul)] = 1.0
+            ig += mul
+        c = (G, Bg.to(device))
+        _consts[key] = c
+    return c
 
 
 def gate(x, S, gated_layout, c_silu, c_sig):
     """[scalars | gates | gated] -> [c_silu silu(scalars) | gated * c_sig sigmoid(gates)]
     [ref: nets/fast_activation.py:132-148]."""
-    G = sum(m for m, _ in gated_layout.segs)
-    outs = [c_silu * torch.nn.functional.silu(x[:, :S])]
-    gates = c_sig * torch.sigmoid(x[:, S:S + G])
-    ig = 0
-    for (mul, l), off in zip(gated_layout.segs, gated_layout.offsets):
-        d = 2 * l + 1
-        blk = x[:, S + G + off:S + G + off + mul * d].reshape(-1, d, mul) * gates[:, None, ig:ig + mul]
-        outs.append(blk.reshape(-1, mul * d))
-        ig += mul
-    return torch.cat(outs, dim=1)
+    G, Bg = _gate_consts(S, gated_layout, x.device, x.dtype)
+    gates = torch.sigmoid(x[:, S:S + G]) @ Bg
+    return torch.cat([c_silu * torch.nn.functional.silu(x[:, :S]), x[:, S + G:] * gates * c_sig], dim=1)
 
 
 def scaled_silu(x, c):
@@ -87,12 +121,16 @@ def alpha_logits(a, alpha_dot, H, Kh, c):
 
 
 def head_of_column(layout, H, device):
-    idx = []
-    for (mul, l) in layout.segs:
-        mh = mul // H
-        for _m in range(2 * l + 1):
-            idx.extend(u // mh for u in range(mul))
-    return torch.tensor(idx, dtype=torch.long, device=device)
+    key = ("hoc", layout.irreps.__repr__(), H, str(device))
+    t = _consts.get(key)
+    if t is None:
+        idx = []
+        for (mul, l) in layout.segs:
+            mh = mul // H
+            for _m in range(2 * l + 1):
+                idx.extend(u // mh for u in range(mul))
+        t = _consts[key] = torch.tensor(idx, dtype=torch.long, device=device)
+    return t
 
 
 def attn_aggregate(logit, value, graph, H, layout):
