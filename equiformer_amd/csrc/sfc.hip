@@ -37,7 +37,12 @@ unsigned long long* g_sfc_dbg = nullptr;  // set by eqf_sfc_debug_buffer (develo
 // 8-12 % faster for bwd_weight, 0-6 % for bwd_data, and 0-14 % SLOWER for fwd (its workgroups of one degree share the
 // staged weight slabs, which the degree-major order keeps hot).  eqf_sfc_debug_order overrides all three for A/B runs.
 int g_sfc_order[3] = {0, 1, 1};
-bool g_sfc_x6_default = true;  // forward matrix step: split-precision bf16 x 6 (true) or exact-fp32 MFMA (false)
+// forward matrix step: exact-fp32 MFMA (false) or split-precision bf16 x 6 (true).  The split-precision step is OFF:
+// at the bench size (E = 25 k edges) it returns run-to-run different results in ~1 % of the launches (one VGPR of the
+// generation phase clobbered in lanes 48..63 -> two rows of an edge tile wrong by ~10 %; tools/sfc_race.py,
+// gpurun_out/r2a, r2b).  It passed every test at E <= 333, which is how it shipped in round 1.  Not root-caused; kept
+// behind eqf_sfc_debug_exp(64) for that investigation only.
+bool g_sfc_x6_default = false;
 int g_sfc_exp = 0;  // development aid (eqf_sfc_debug_exp): bit mask that switches phases of the kernels OFF to time the rest
 
 constexpr int SFC_MAX_DEG = 4;
@@ -200,22 +205,12 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& p1, bf16x8& 
 template <int D3, int NT, int FT>
 __device__ __forceinline__ void f_mma6(const int (&arow)[FT], const int (&bcol)[FT], f32x16 (&acc)[FT]) {
   constexpr int F_SB = f_sb(D3, FT);
-  // consecutive tiles of a wave often share their row tile (degree 0: two row tiles, many column tiles) or their
-  // column tile (degree 2: one column tile): the split fragments of the shared operand are then reused -- the split is
-  // the VALU cost of this step (44 instructions per fragment).  The flags are wave-uniform.
-  bool same_a[NT], same_b[NT];
-  same_a[0] = same_b[0] = false;
-#pragma unroll
-  for (int i = 1; i < NT; ++i) {
-    same_a[i] = __builtin_amdgcn_readfirstlane((int)(arow[i] == arow[i - 1])) != 0;
-    same_b[i] = __builtin_amdgcn_readfirstlane((int)(bcol[i] == bcol[i - 1])) != 0;
-  }
 #pragma unroll
   for (int kg = 0; kg < 2; ++kg) {  // two groups of 16 k per 32-channel slab
     bf16x8 x1, x2, x3, y1, y2, y3;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      if (!same_a[i]) {
+      {
         float av[8];
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg]);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg + 4]);
@@ -223,7 +218,7 @@ __device__ __forceinline__ void f_mma6(const int (&arow)[FT], const int (&bcol)[
         for (int j = 0; j < 4; ++j) av[j] = a0[j], av[4 + j] = a1[j];
         split3(av, x1, x2, x3);
       }
-      if (!same_b[i]) {
+      {
         float bw[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) bw[j] = sfc_lds[bcol[i] + (16 * kg + j) * F_SB];
@@ -1156,6 +1151,8 @@ int eqf_sfc_debug_order(int mode) {
   g_sfc_order[1] = g_sfc_order[2] = mode < 0 ? 1 : mode;
   return 0;
 }
+
+int eqf_sfc_debug_x6_default(void) { return g_sfc_x6_default ? 1 : 0; }
 
 int eqf_sfc_debug_exp(int mask) {
   g_sfc_exp = mask;
