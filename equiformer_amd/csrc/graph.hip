@@ -2,6 +2,7 @@
 // radial basis.  Molecules are tiny (N ~ 18-80 atoms), so one workgroup owns one molecule and brute-forces its
 // pairs out of L1; the output is already sorted by destination (the order the segmented kernels want).
 #include "common.h"
+#include "geom.h"
 
 namespace {
 
@@ -247,22 +248,7 @@ __global__ __launch_bounds__(256) void csr_by_source_kernel(const int* __restric
   }
 }
 
-// raw (norm-normalised) real spherical harmonics l = 2 and their gradients wrt the unit vector
-struct SH2 {
-  float v[5];
-  float g[5][3];
-};
-__device__ __forceinline__ SH2 sh2_of(float x, float y, float z) {
-  const float s3 = 1.7320508075688772f;
-  SH2 s;
-  s.v[0] = s3 * x * z, s.g[0][0] = s3 * z, s.g[0][1] = 0.f, s.g[0][2] = s3 * x;
-  s.v[1] = s3 * x * y, s.g[1][0] = s3 * y, s.g[1][1] = s3 * x, s.g[1][2] = 0.f;
-  s.v[2] = y * y - 0.5f * (x * x + z * z), s.g[2][0] = -x, s.g[2][1] = 2.f * y, s.g[2][2] = -z;
-  s.v[3] = s3 * y * z, s.g[3][0] = 0.f, s.g[3][1] = s3 * z, s.g[3][2] = s3 * y;
-  s.v[4] = 0.5f * s3 * (z * z - x * x), s.g[4][0] = -s3 * x, s.g[4][1] = 0.f, s.g[4][2] = s3 * z;
-  return s;
-}
-
+// spherical harmonics / edge length and their gradient: geom.h (shared with the second-derivative kernel)
 __global__ __launch_bounds__(256) void edge_geom_fwd_kernel(const float* __restrict__ pos, const int* __restrict__ src,
                                                             const int* __restrict__ dst,
                                                             const float* __restrict__ offsets, int E, int lmax,
@@ -274,35 +260,13 @@ __global__ __launch_bounds__(256) void edge_geom_fwd_kernel(const float* __restr
   float vx = pos[3 * s] - pos[3 * d], vy = pos[3 * s + 1] - pos[3 * d + 1], vz = pos[3 * s + 2] - pos[3 * d + 2];
   if (offsets) vx += offsets[3 * e], vy += offsets[3 * e + 1], vz += offsets[3 * e + 2];
   vec[3 * e] = vx, vec[3 * e + 1] = vy, vec[3 * e + 2] = vz;
-  const float L = sqrtf(vx * vx + vy * vy + vz * vz);
-  len[e] = L;
-  const float inv = 1.f / fmaxf(L, 1e-12f);
-  const float x = vx * inv, y = vy * inv, z = vz * inv;
+  float o[16];
+  len[e] = geom_sh<float>(vx, vy, vz, lmax, o);
   const int S = (lmax + 1) * (lmax + 1);
-  float* o = sh + (long)e * S;
-  o[0] = 1.f;
-  if (lmax >= 1) {
-    const float c1 = 1.7320508075688772f;
-    o[1] = c1 * x, o[2] = c1 * y, o[3] = c1 * z;
-  }
-  if (lmax >= 2) {
-    const float c2 = 2.23606797749979f;
-    const SH2 s2 = sh2_of(x, y, z);
+  float* out = sh + (long)e * S;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) o[4 + i] = c2 * s2.v[i];
-    if (lmax >= 3) {
-      const float c3 = 2.6457513110645907f;
-      const float y2 = y * y, x2z2 = x * x + z * z;
-      const float a = 0.9128709291752769f /* sqrt(5/6) */, b5 = 2.23606797749979f, c38 = 0.6123724356957945f;
-      o[9] = c3 * a * (s2.v[0] * z + s2.v[4] * x);
-      o[10] = c3 * b5 * s2.v[0] * y;
-      o[11] = c3 * c38 * (4.f * y2 - x2z2) * x;
-      o[12] = c3 * 0.5f * y * (2.f * y2 - 3.f * x2z2);
-      o[13] = c3 * c38 * z * (4.f * y2 - x2z2);
-      o[14] = c3 * b5 * s2.v[4] * y;
-      o[15] = c3 * a * (s2.v[4] * z - s2.v[0] * x);
-    }
-  }
+  for (int i = 0; i < 16; ++i)
+    if (i < S) out[i] = o[i];
 }
 
 __global__ __launch_bounds__(256) void edge_geom_bwd_kernel(const float* __restrict__ vec, const float* __restrict__ d_sh,
@@ -310,67 +274,10 @@ __global__ __launch_bounds__(256) void edge_geom_bwd_kernel(const float* __restr
                                                             float* __restrict__ d_vec) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const float vx = vec[3 * e], vy = vec[3 * e + 1], vz = vec[3 * e + 2];
-  const float L = sqrtf(vx * vx + vy * vy + vz * vz);
-  const float inv = 1.f / fmaxf(L, 1e-12f);
-  const float x = vx * inv, y = vy * inv, z = vz * inv;
-  float gx = 0.f, gy = 0.f, gz = 0.f;  // gradient wrt the unit vector
-  if (d_sh) {
-    const int S = (lmax + 1) * (lmax + 1);
-    const float* g = d_sh + (long)e * S;
-    if (lmax >= 1) {
-      const float c1 = 1.7320508075688772f;
-      gx += c1 * g[1], gy += c1 * g[2], gz += c1 * g[3];
-    }
-    if (lmax >= 2) {
-      const float c2 = 2.23606797749979f;
-      const SH2 s2 = sh2_of(x, y, z);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const float t = c2 * g[4 + i];
-        gx += t * s2.g[i][0], gy += t * s2.g[i][1], gz += t * s2.g[i][2];
-      }
-      if (lmax >= 3) {
-        const float c3 = 2.6457513110645907f;
-        const float y2 = y * y, x2z2 = x * x + z * z;
-        const float a = 0.9128709291752769f, b5 = 2.23606797749979f, c38 = 0.6123724356957945f;
-        const float q = 4.f * y2 - x2z2;
-        float t;
-        // t0 = a (s0 z + s4 x)
-        t = c3 * a * g[9];
-        gx += t * (s2.g[0][0] * z + s2.g[4][0] * x + s2.v[4]);
-        gy += t * (s2.g[0][1] * z + s2.g[4][1] * x);
-        gz += t * (s2.g[0][2] * z + s2.v[0] + s2.g[4][2] * x);
-        // t1 = sqrt5 s0 y
-        t = c3 * b5 * g[10];
-        gx += t * s2.g[0][0] * y, gy += t * (s2.g[0][1] * y + s2.v[0]), gz += t * s2.g[0][2] * y;
-        // t2 = c38 q x
-        t = c3 * c38 * g[11];
-        gx += t * (q - 2.f * x * x), gy += t * (8.f * y * x), gz += t * (-2.f * z * x);
-        // t3 = .5 y (2 y2 - 3 x2z2)
-        t = c3 * 0.5f * g[12];
-        gx += t * (-6.f * x * y), gy += t * (2.f * y2 - 3.f * x2z2 + 4.f * y2), gz += t * (-6.f * z * y);
-        // t4 = c38 z q
-        t = c3 * c38 * g[13];
-        gx += t * (-2.f * x * z), gy += t * (8.f * y * z), gz += t * (q - 2.f * z * z);
-        // t5 = sqrt5 s4 y
-        t = c3 * b5 * g[14];
-        gx += t * s2.g[4][0] * y, gy += t * (s2.g[4][1] * y + s2.v[4]), gz += t * s2.g[4][2] * y;
-        // t6 = a (s4 z - s0 x)
-        t = c3 * a * g[15];
-        gx += t * (s2.g[4][0] * z - s2.g[0][0] * x - s2.v[0]);
-        gy += t * (s2.g[4][1] * z - s2.g[0][1] * x);
-        gz += t * (s2.g[4][2] * z + s2.v[4] - s2.g[0][2] * x);
-      }
-    }
-  }
-  // d unit / d vec = (I - u u^T) / L
-  const float ug = x * gx + y * gy + z * gz;
-  float ox = (gx - x * ug) * inv, oy = (gy - y * ug) * inv, oz = (gz - z * ug) * inv;
-  if (d_len) {
-    const float gl = d_len[e];
-    ox += gl * x, oy += gl * y, oz += gl * z;
-  }
+  const int S = (lmax + 1) * (lmax + 1);
+  float ox, oy, oz;
+  geom_grad<float>(vec[3 * e], vec[3 * e + 1], vec[3 * e + 2], lmax, d_sh ? d_sh + (long)e * S : nullptr, d_len != nullptr,
+                   d_len ? d_len[e] : 0.f, ox, oy, oz);
   d_vec[3 * e] = ox, d_vec[3 * e + 1] = oy, d_vec[3 * e + 2] = oz;
 }
 

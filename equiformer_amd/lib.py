@@ -95,6 +95,17 @@ SIGNATURES = {
     "eqf_alpha_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
     "eqf_attn_aggregate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp],
     "eqf_attn_aggregate_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp],
+    "eqf_silu_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, _long, _f, c_fp],
+    "eqf_gate_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _f, c_fp],
+    "eqf_lnsilu_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _f, c_fp],
+    "eqf_layernorm_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, _f, c_fp],
+    "eqf_alpha_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
+    "eqf_attn_aggregate_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64,
+                                c_fp],
+    "eqf_rbf_expnorm_bwd2": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, _f, _f, c_fp, c_fp, c_fp],
+    "eqf_rbf_gaussian_bwd2": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp, c_fp, c_fp,
+                              c_fp, c_fp],
+    "eqf_edge_geom_bwd2": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
     "eqf_prof_enable": [ctypes.c_char_p],
     "eqf_prof_report": [ctypes.c_char_p, c_int],
 }

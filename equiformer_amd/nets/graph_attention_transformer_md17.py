@@ -5,12 +5,14 @@ Drop-in for the reference's nets/graph_attention_transformer_md17.py (`GraphAtte
 `torch.no_grad()`, reads `task_mean/task_std`.
 
 In training mode the forces are produced with `create_graph=True` (reference: nets/graph_attention_transformer_md17.py:
-318-325), i.e. `loss.backward()` on a force loss is a second-order pass; see `equiformer_amd/second_order.py` for how
-the HIP operators support it.  In eval mode (force evaluation, main_md17.py:444-452) the forces come from the plain
+318-325), i.e. `loss.backward()` on a force loss is a second-order pass: every operator's backward is then itself a
+differentiable HIP operator (`ops._*Bwd`, kernels `eqf_*_bwd2` in csrc/second.hip; multilinear operators reuse their
+first-order kernels).  In eval mode (force evaluation, main_md17.py:444-452) the forces come from the plain
 first-order HIP backward and carry no graph.
 """
 import torch
 
+from .. import ops
 from ..graph import EdgeGraph
 from ..irreps import Irreps
 from .graph_attention_transformer import _Trunk
@@ -65,8 +67,9 @@ class GraphAttentionTransformerMD17(_Trunk):
             energy = self.scale * energy
         trainable = any(p.requires_grad for p in self.parameters())
         second_order = self.training and trainable
-        forces = -1 * torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), create_graph=second_order,
-                                          retain_graph=trainable)[0]
+        with ops.input_grads_only():  # only d E / d pos is wanted here: no parameter gradients in this pass
+            forces = -1 * torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy),
+                                              create_graph=second_order, retain_graph=trainable)[0]
         return energy, forces
 
 
@@ -84,7 +87,7 @@ def _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, **over):
 @register_model
 def graph_attention_transformer_nonlinear_l2_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
                                                   task_std=None, **kwargs):
-    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, basis_type="gaussian", alpha_drop=0.0)
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, basis_type="gaussian", alpha_drop=0.2)
 
 
 @register_model

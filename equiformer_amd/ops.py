@@ -12,7 +12,6 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import lib
-from . import second_order as so
 from .lib import EqfGemmDesc, EqfRows, call
 
 
@@ -21,6 +20,36 @@ class HipOnlyError(RuntimeError):
 
 
 _dummy = {}
+_input_grads_only = [False]
+
+
+class input_grads_only:
+    """Context of a `torch.autograd.grad(energy, pos, create_graph=True)` force pass
+    [ref: nets/graph_attention_transformer_md17.py:318-325]: only gradients wrt operator INPUTS are wanted, so the
+    differentiable (create_graph) backward of every operator skips its parameter gradients -- `needs_input_grad` cannot
+    tell, it is static.  Outside this context the create_graph backward also returns the parameter gradients
+    (first-order kernels; differentiating THROUGH those raises)."""
+
+    def __enter__(self):
+        self.prev = _input_grads_only[0]
+        _input_grads_only[0] = True
+
+    def __exit__(self, *exc):
+        _input_grads_only[0] = self.prev
+        return False
+
+
+def _want_param_grads():
+    return not _input_grads_only[0]
+
+
+def _guard_opt(t, dep, what):
+    """First-order parameter gradient handed out by a create_graph backward: usable as a value, raises when something
+    tries to differentiate through it (second derivatives wrt parameters-of-parameters are not implemented)."""
+    if t is None:
+        return None
+    return _Guard.apply(t, dep, what) if dep.requires_grad else t
+
 
 
 def _nonnull(t):
@@ -133,9 +162,10 @@ class _LayerNorm(Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, rstd, mean0, bias = ctx.saved_tensors
-        if torch.is_grad_enabled():  # create_graph: differentiable restatement (second_order.py)
-            gx, gw, gb = so.vjp(lambda a, b, c: so.layer_norm(a, b, c, ctx.layout, ctx.eps), [x, weight, bias], dy)
-            return gx, gw, gb, None, None
+        if torch.is_grad_enabled():  # create_graph: the backward is itself a differentiable HIP operator
+            dx, dw, db = _LayerNormBwd.apply(x, weight, dy, rstd, mean0, ctx.layout, ctx.eps, ctx.nb)
+            return dx, _guard_opt(dw, dy, "layer-norm weight gradient"), _guard_opt(db, dy, "layer-norm bias gradient"), \
+                None, None
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
@@ -143,6 +173,39 @@ class _LayerNorm(Function):
         call("eqf_layernorm_bwd", _p(x), _p(weight), _p(dy), _p(rstd), _p(mean0), _p(dx), _p(dw), _p(db), x.shape[0],
              ctx.layout.c_ref, _stream())
         return dx, dw, db, None, None
+
+
+class _LayerNormBwd(Function):
+    """dx (and, outside a force pass, the first-order dw / db) of the equivariant layer norm as a differentiable op;
+    its backward is eqf_layernorm_bwd2."""
+
+    @staticmethod
+    def forward(ctx, x, weight, dy, rstd, mean0, layout, eps, nb):
+        dy = _c(dy)
+        _chk(dy)
+        dx = torch.empty_like(x)
+        want = _want_param_grads()
+        dw, db = _zeros2(weight.numel(), nb, x.device) if want else (None, None)
+        call("eqf_layernorm_bwd", _p(x), _p(weight), _p(dy), _p(rstd), _p(mean0), _p(dx), _p(dw), _p(db), x.shape[0],
+             layout.c_ref, _stream())
+        ctx.save_for_backward(x, weight, dy)
+        ctx.layout, ctx.eps = layout, eps
+        if not want:
+            return dx, None, None
+        ctx.mark_non_differentiable(dw, db)
+        return dx, dw, db
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c, _cw=None, _cb=None):
+        x, weight, dy = ctx.saved_tensors
+        c = _c(c)
+        _chk(c)
+        g_x, g_dy = torch.empty_like(x), torch.empty_like(x)
+        g_w = _zeros_like(weight)
+        call("eqf_layernorm_bwd2", _p(x), _p(weight), _p(dy), _p(c), _p(g_x), _p(g_w), _p(g_dy), x.shape[0],
+             ctx.layout.c_ref, float(ctx.eps), _stream())
+        return g_x, g_w, g_dy, None, None, None, None, None
 
 
 def layer_norm(x, weight, bias, layout, eps=1e-5):
@@ -297,6 +360,8 @@ class _IrrepsLinear(Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if torch.is_grad_enabled():  # create_graph: every piece is itself differentiable
             dx = _LinDgrad.apply(dy, weight, spec) if ctx.needs_input_grad[0] else None
+            if not _want_param_grads():
+                return dx, None, None, None
             dw = _LinWgrad.apply(x, dy, spec) if ctx.needs_input_grad[1] else None
             db = None
             if want_b:
@@ -312,6 +377,8 @@ class _IrrepsLinear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _lin_dgrad(dy, weight, spec)
+        if not _want_param_grads():  # force evaluation: d E / d pos only
+            return dx, None, None, None
         if ctx.needs_input_grad[1] or want_b:
             dw_, db_ = _zeros2(weight.numel(), spec.bias_dim if want_b else 0, x.device)
         fused_b = want_b and ctx.needs_input_grad[1] and any(l == 0 and N == spec.bias_dim
@@ -411,6 +478,8 @@ class _DenseLinear(Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if torch.is_grad_enabled():  # create_graph
             dx = _DenseDgrad.apply(dy, weight) if ctx.needs_input_grad[0] else None
+            if not _want_param_grads():
+                return dx, None, None
             dw = _DenseWgrad.apply(x, dy) if ctx.needs_input_grad[1] else None
             db = dy.sum(0) if want_b else None
             return dx, dw, db
@@ -422,6 +491,8 @@ class _DenseLinear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _dense_dgrad(dy, weight)
+        if not _want_param_grads():  # force evaluation
+            return dx, None, None
         if ctx.needs_input_grad[1] or want_b:
             dw_, db_ = _zeros2(weight.numel(), N if want_b else 0, x.device)
         if ctx.needs_input_grad[1]:
@@ -458,13 +529,36 @@ class _Gate(Function):
         (x,) = ctx.saved_tensors
         S, gated_layout, c_silu, c_sig = ctx.args
         if torch.is_grad_enabled():  # create_graph
-            (gx,) = so.vjp(lambda a: so.gate(a, S, gated_layout, c_silu, c_sig), [x], dy)
-            return gx, None, None, None, None
+            return _GateBwd.apply(x, dy, S, gated_layout, c_silu, c_sig), None, None, None, None
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
         call("eqf_gate_bwd", _p(x), _p(dy), _p(dx), x.shape[0], S, gated_layout.c_ref, c_silu, c_sig, _stream())
         return dx, None, None, None, None
+
+
+class _GateBwd(Function):
+    @staticmethod
+    def forward(ctx, x, dy, S, gated_layout, c_silu, c_sig):
+        dy = _c(dy)
+        _chk(dy)
+        dx = torch.empty_like(x)
+        call("eqf_gate_bwd", _p(x), _p(dy), _p(dx), x.shape[0], S, gated_layout.c_ref, c_silu, c_sig, _stream())
+        ctx.save_for_backward(x, dy)
+        ctx.args = (S, gated_layout, c_silu, c_sig)
+        return dx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c):
+        x, dy = ctx.saved_tensors
+        S, gated_layout, c_silu, c_sig = ctx.args
+        c = _c(c)
+        _chk(c)
+        g_x, g_dy = torch.empty_like(x), torch.empty_like(dy)
+        call("eqf_gate_bwd2", _p(x), _p(dy), _p(c), _p(g_x), _p(g_dy), x.shape[0], S, gated_layout.c_ref, c_silu, c_sig,
+             _stream())
+        return g_x, g_dy, None, None, None, None
 
 
 def gate(x, S, gated_layout, c_silu, c_sig):
@@ -486,13 +580,34 @@ class _ScaledSilu(Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         if torch.is_grad_enabled():  # create_graph
-            (gx,) = so.vjp(lambda a: so.scaled_silu(a, ctx.c), [x], dy)
-            return gx, None
+            return _ScaledSiluBwd.apply(x, dy, ctx.c), None
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
         call("eqf_silu_bwd", _p(x), _p(dy), _p(dx), x.numel(), ctx.c, _stream())
         return dx, None
+
+
+class _ScaledSiluBwd(Function):
+    @staticmethod
+    def forward(ctx, x, dy, c0):
+        dy = _c(dy)
+        _chk(dy)
+        dx = torch.empty_like(x)
+        call("eqf_silu_bwd", _p(x), _p(dy), _p(dx), x.numel(), c0, _stream())
+        ctx.save_for_backward(x, dy)
+        ctx.c0 = c0
+        return dx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c):
+        x, dy = ctx.saved_tensors
+        c = _c(c)
+        _chk(c)
+        g_x, g_dy = torch.empty_like(x), torch.empty_like(x)
+        call("eqf_silu_bwd2", _p(x), _p(dy), _p(c), _p(g_x), _p(g_dy), x.numel(), ctx.c0, _stream())
+        return g_x, g_dy, None
 
 
 def scaled_silu(x, c):
@@ -514,8 +629,8 @@ class _LnSilu(Function):
     def backward(ctx, dy):
         x, gamma, beta = ctx.saved_tensors
         if torch.is_grad_enabled():  # create_graph
-            gx, gg, gb = so.vjp(lambda a, b, c: so.ln_silu(a, b, c, ctx.eps), [x, gamma, beta], dy)
-            return gx, gg, gb, None
+            dx, dg, db = _LnSiluBwd.apply(x, gamma, beta, dy, ctx.eps)
+            return dx, _guard_opt(dg, dy, "LayerNorm weight gradient"), _guard_opt(db, dy, "LayerNorm bias gradient"), None
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
@@ -523,6 +638,35 @@ class _LnSilu(Function):
         call("eqf_lnsilu_bwd", _p(x), _p(gamma), _p(beta), _p(dy), _p(dx), _p(dg), _p(db), x.shape[0], x.shape[1],
              ctx.eps, _stream())
         return dx, dg, db, None
+
+
+class _LnSiluBwd(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, dy, eps):
+        dy = _c(dy)
+        _chk(dy)
+        dx = torch.empty_like(x)
+        dg, db = _zeros2(gamma.numel(), beta.numel(), x.device)
+        call("eqf_lnsilu_bwd", _p(x), _p(gamma), _p(beta), _p(dy), _p(dx), _p(dg), _p(db), x.shape[0], x.shape[1], eps,
+             _stream())
+        ctx.save_for_backward(x, gamma, beta, dy)
+        ctx.eps = eps
+        if not _want_param_grads():
+            return dx, None, None
+        ctx.mark_non_differentiable(dg, db)
+        return dx, dg, db
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c, _cg=None, _cb=None):
+        x, gamma, beta, dy = ctx.saved_tensors
+        c = _c(c)
+        _chk(c)
+        g_x, g_dy = torch.empty_like(x), torch.empty_like(x)
+        g_g, g_b = _zeros2(gamma.numel(), beta.numel(), x.device)
+        call("eqf_lnsilu_bwd2", _p(x), _p(gamma), _p(beta), _p(dy), _p(c), _p(g_x), _p(g_g), _p(g_b), _p(g_dy),
+             x.shape[0], x.shape[1], ctx.eps, _stream())
+        return g_x, g_g, g_b, g_dy, None
 
 
 def ln_silu(x, gamma, beta, eps=1e-5):
@@ -717,19 +861,58 @@ class _EdgeGeom(Function):
         vec, pos_in = ctx.saved_tensors
         g = ctx.graph
         if torch.is_grad_enabled():  # create_graph
-            (gpos,) = so.vjp(lambda p: so.edge_geometry(p, ctx.offsets, g, ctx.lmax), [pos_in], (dlen, dsh))
-            return gpos, None, None, None
+            return _EdgeGeomBwd.apply(pos_in, vec, dlen, dsh, g, ctx.lmax), None, None, None
         dlen = _c(dlen) if dlen is not None else None
         dsh = _c(dsh) if dsh is not None else None
         _chk(dlen, dsh)
+        return _edge_geom_dpos(vec, dsh, dlen, g, ctx.lmax, ctx.n), None, None, None
+
+
+def _edge_geom_dpos(vec, dsh, dlen, g, lmax, n):
+    st = _stream()
+    dvec = torch.empty_like(vec)
+    call("eqf_edge_geom_bwd", _p(vec), _p(dsh), _p(dlen), g.E, lmax, _p(dvec), st)
+    # d pos[n] = sum_{src(e)=n} dvec[e] - sum_{dst(e)=n} dvec[e]   (segmented, no atomics)
+    dpos = torch.empty((n, 3), device=vec.device, dtype=torch.float32)
+    call("eqf_segment_sum", _p(dvec), _p(g.src_ptr), _p(g.src_perm), _p(dpos), n, 3, 1.0, 0, st)
+    call("eqf_segment_sum", _p(dvec), _p(g.row_ptr), None, _p(dpos), n, 3, -1.0, 1, st)
+    return dpos
+
+
+class _EdgeGeomBwd(Function):
+    """d_pos from (d_len, d_sh) as a differentiable op.  `vec` is the saved edge vector pos[src] - pos[dst] (+ offsets);
+    its dependence on `pos` is accounted for here (the backward returns the gradient wrt pos)."""
+
+    @staticmethod
+    def forward(ctx, pos, vec, dlen, dsh, graph, lmax):
+        dlen = _c(dlen) if dlen is not None else None
+        dsh = _c(dsh) if dsh is not None else None
+        _chk(dlen, dsh)
+        ctx.save_for_backward(vec, dlen, dsh)
+        ctx.graph, ctx.lmax, ctx.n = graph, lmax, pos.shape[0]
+        return _edge_geom_dpos(vec, dsh, dlen, graph, lmax, pos.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c_pos):
+        vec, dlen, dsh = ctx.saved_tensors
+        g, lmax, n = ctx.graph, ctx.lmax, ctx.n
+        c_pos = _c(c_pos)
+        _chk(c_pos)
         st = _stream()
-        dvec = torch.empty_like(vec)
-        call("eqf_edge_geom_bwd", _p(vec), _p(dsh), _p(dlen), g.E, ctx.lmax, _p(dvec), st)
-        # d pos[n] = sum_{src(e)=n} dvec[e] - sum_{dst(e)=n} dvec[e]   (segmented, no atomics)
-        dpos = torch.empty((ctx.n, 3), device=vec.device, dtype=torch.float32)
-        call("eqf_segment_sum", _p(dvec), _p(g.src_ptr), _p(g.src_perm), _p(dpos), ctx.n, 3, 1.0, 0, st)
-        call("eqf_segment_sum", _p(dvec), _p(g.row_ptr), None, _p(dpos), ctx.n, 3, -1.0, 1, st)
-        return dpos, None, None, None
+        E = g.E
+        # cotangent of d_vec: c_pos[src] - c_pos[dst]  (the edge-vector kernel applied to c_pos, lmax = 0)
+        c_vec = torch.empty((E, 3), device=vec.device, dtype=torch.float32)
+        scratch = torch.empty((2 * E,), device=vec.device, dtype=torch.float32)
+        call("eqf_edge_geom_fwd", _p(c_pos), _p(g.src), _p(g.dst), None, E, 0, _p(c_vec), _p(scratch), _p(scratch, E), st)
+        g_vec = torch.empty_like(vec)
+        g_dsh = torch.empty_like(dsh) if dsh is not None else None
+        g_dlen = torch.empty_like(dlen) if dlen is not None else None
+        call("eqf_edge_geom_bwd2", _p(vec), _p(dsh), _p(dlen), _p(c_vec), E, lmax, _p(g_vec), _p(g_dsh), _p(g_dlen), st)
+        g_pos = torch.empty((n, 3), device=vec.device, dtype=torch.float32)
+        call("eqf_segment_sum", _p(g_vec), _p(g.src_ptr), _p(g.src_perm), _p(g_pos), n, 3, 1.0, 0, st)
+        call("eqf_segment_sum", _p(g_vec), _p(g.row_ptr), None, _p(g_pos), n, 3, -1.0, 1, st)
+        return g_pos, None, g_dlen, g_dsh, None, None
 
 
 def edge_geometry(pos, offsets, graph, lmax):
@@ -750,18 +933,55 @@ class _RbfGaussian(Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
         length, mean, std, weight, bias = ctx.saved_tensors
+        if torch.is_grad_enabled() and ctx.needs_input_grad[0]:  # create_graph (forces of a gaussian-basis MD17 model)
+            outs = _RbfGaussianBwd.apply(length, mean, std, weight, bias, dout, ctx.cutoff)
+            return (outs[0],) + tuple(_guard_opt(t, dout, "radial-basis parameter gradient") for t in outs[1:]) + (None,)
         dout = _c(dout)
         _chk(dout)
+        return _rbf_gaussian_bwd(length, mean, std, weight, bias, dout, ctx.cutoff, ctx.needs_input_grad[0]) + (None,)
+
+
+def _rbf_gaussian_bwd(length, mean, std, weight, bias, dout, cutoff, want_len):
+    E, R = length.shape[0], mean.numel()
+    dm, ds = _zeros_like(mean), _zeros_like(std)
+    dw, db = _zeros_like(weight), _zeros_like(bias)
+    dlen = torch.empty_like(length) if want_len else None
+    call("eqf_rbf_gaussian_bwd", _p(length), _p(dout), E, R, _p(mean), _p(std), _p(weight), _p(bias), cutoff,
+         _p(dm), _p(ds), _p(dw), _p(db), _p(dlen), _stream())
+    return dlen, dm, ds, dw, db
+
+
+class _RbfGaussianBwd(Function):
+    """(d_len, first-order parameter gradients) of the Gaussian basis as a differentiable op: only d_len carries a
+    cotangent in the force graph; its backward is eqf_rbf_gaussian_bwd2."""
+
+    @staticmethod
+    def forward(ctx, length, mean, std, weight, bias, dout, cutoff):
+        dout = _c(dout)
+        _chk(dout)
+        dlen, dm, ds, dw, db = _rbf_gaussian_bwd(length, mean, std, weight, bias, dout, cutoff, True)
+        ctx.save_for_backward(length, mean, std, weight, bias, dout)
+        ctx.cutoff = cutoff
+        if not _want_param_grads():
+            return dlen, None, None, None, None
+        ctx.mark_non_differentiable(dm, ds, dw, db)
+        return dlen, dm, ds, dw, db
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c_len, *_unused):
+        length, mean, std, weight, bias, dout = ctx.saved_tensors
+        c_len = _c(c_len)
+        _chk(c_len)
         E, R = length.shape[0], mean.numel()
-        dm, ds = _zeros_like(mean), _zeros_like(std)
-        dw, db = _zeros_like(weight), _zeros_like(bias)
-        dlen = torch.empty_like(length) if ctx.needs_input_grad[0] else None
-        call("eqf_rbf_gaussian_bwd", _p(length), _p(dout), E, R, _p(mean), _p(std), _p(weight), _p(bias), ctx.cutoff,
-             _p(dm), _p(ds), _p(dw), _p(db), _p(dlen), _stream())
-        return dlen, dm, ds, dw, db, None
+        g_len, g_dout = torch.empty_like(length), torch.empty_like(dout)
+        g_m, g_s = _zeros_like(mean), _zeros_like(std)
+        g_w, g_b = _zeros_like(weight), _zeros_like(bias)
+        call("eqf_rbf_gaussian_bwd2", _p(length), _p(dout), _p(c_len), E, R, _p(mean), _p(std), _p(weight), _p(bias),
+             ctx.cutoff, _p(g_len), _p(g_dout), _p(g_m), _p(g_s), _p(g_w), _p(g_b), _stream())
+        return g_len, g_m, g_s, g_w, g_b, g_dout, None
 
 
 def rbf_gaussian(length, mean, std, weight, bias, cutoff):
@@ -785,14 +1005,37 @@ class _RbfExpNorm(Function):
         if not ctx.needs_input_grad[0]:
             return None, None, None, None, None
         if torch.is_grad_enabled():  # create_graph
-            (gl,) = so.vjp(lambda a: so.rbf_expnorm(a, means, betas, ctx.args[0], ctx.args[1]), [length], dout)
-            return gl, None, None, None, None
+            return _RbfExpNormBwd.apply(length, dout, means, betas, ctx.args[0], ctx.args[1]), None, None, None, None
         dout = _c(dout)
         _chk(dout)
         dlen = torch.empty_like(length)
         call("eqf_rbf_expnorm_bwd", _p(length), _p(dout), length.shape[0], means.numel(), _p(means), _p(betas),
              ctx.args[0], ctx.args[1], _p(dlen), _stream())
         return dlen, None, None, None, None
+
+
+class _RbfExpNormBwd(Function):
+    @staticmethod
+    def forward(ctx, length, dout, means, betas, alpha, cutoff):
+        dout = _c(dout)
+        _chk(dout)
+        dlen = torch.empty_like(length)
+        call("eqf_rbf_expnorm_bwd", _p(length), _p(dout), length.shape[0], means.numel(), _p(means), _p(betas), alpha,
+             cutoff, _p(dlen), _stream())
+        ctx.save_for_backward(length, dout, means, betas)
+        ctx.args = (alpha, cutoff)
+        return dlen
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c_len):
+        length, dout, means, betas = ctx.saved_tensors
+        c_len = _c(c_len)
+        _chk(c_len)
+        g_len, g_dout = torch.empty_like(length), torch.empty_like(dout)
+        call("eqf_rbf_expnorm_bwd2", _p(length), _p(dout), _p(c_len), length.shape[0], means.numel(), _p(means),
+             _p(betas), ctx.args[0], ctx.args[1], _p(g_len), _p(g_dout), _stream())
+        return g_len, g_dout, None, None, None, None
 
 
 def rbf_expnorm(length, means, betas, alpha, cutoff):
@@ -1168,6 +1411,8 @@ class _SepFctp(Function):
             # needs_input_grad is static (the parameters always "need" a gradient), so the weight / bias gradients
             # are produced here as well -- first-order kernels, guarded: differentiating THROUGH them is not implemented
             gW = gb = gW2 = gb2 = None
+            if not _want_param_grads():
+                return dx, dM, dw, None, None, None, None, None
             if need[3] or need[5]:
                 with torch.no_grad():
                     gW_ = _zeros_like(weight)
@@ -1200,6 +1445,8 @@ class _SepFctp(Function):
                  spec.out_layout.c_ref, _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, st)
         want_b = ctx.has_bias[0] and need[4]
         want_b2 = ctx.has_bias[1] and need[6]
+        if not _want_param_grads():  # force evaluation
+            return dx, dM, dw, None, None, None, None, None
         if need[3] or need[5] or want_b or want_b2:
             n1_0 = spec.out_layout.mul_of(0)
             sizes = [spec.weight_numel, spec.weight2_numel, n1_0 if want_b else 0, spec.n2 if want_b2 else 0]
@@ -1246,14 +1493,43 @@ class _AlphaLogits(Function):
         a, alpha_dot = ctx.saved_tensors
         H, Kh, c = ctx.args
         if torch.is_grad_enabled():  # create_graph
-            ga, gd = so.vjp(lambda u, v: so.alpha_logits(u, v, H, Kh, c), [a, alpha_dot], dlogit)
-            return ga, gd, None, None, None
+            da, dd = _AlphaLogitsBwd.apply(a, alpha_dot, dlogit, H, Kh, c)
+            return da, _guard_opt(dd, dlogit, "alpha_dot gradient"), None, None, None
         dlogit = _c(dlogit)
         _chk(dlogit)
         da = torch.empty_like(a)
         dd = _zeros_like(alpha_dot)
         call("eqf_alpha_bwd", _p(a), _p(alpha_dot), _p(dlogit), _p(da), _p(dd), a.shape[0], H, Kh, c, _stream())
         return da, dd, None, None, None
+
+
+class _AlphaLogitsBwd(Function):
+    @staticmethod
+    def forward(ctx, a, alpha_dot, dlogit, H, Kh, c):
+        dlogit = _c(dlogit)
+        _chk(dlogit)
+        da = torch.empty_like(a)
+        dd = _zeros_like(alpha_dot)
+        call("eqf_alpha_bwd", _p(a), _p(alpha_dot), _p(dlogit), _p(da), _p(dd), a.shape[0], H, Kh, c, _stream())
+        ctx.save_for_backward(a, alpha_dot, dlogit)
+        ctx.args = (H, Kh, c)
+        if not _want_param_grads():
+            return da, None
+        ctx.mark_non_differentiable(dd)
+        return da, dd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ca, _cd=None):
+        a, alpha_dot, dlogit = ctx.saved_tensors
+        H, Kh, c = ctx.args
+        ca = _c(ca)
+        _chk(ca)
+        g_a, g_dl = torch.empty_like(a), torch.empty_like(dlogit)
+        g_ad = _zeros_like(alpha_dot)
+        call("eqf_alpha_bwd2", _p(a), _p(alpha_dot), _p(dlogit), _p(ca), _p(g_a), _p(g_ad), _p(g_dl), a.shape[0], H, Kh, c,
+             _stream())
+        return g_a, g_ad, g_dl, None, None, None
 
 
 def alpha_logits(a, alpha_dot, H, Kh, c):
@@ -1278,11 +1554,9 @@ class _AttnAggregate(Function):
     def backward(ctx, dout):
         alpha, value, logit = ctx.saved_tensors
         graph, H, layout, drop_p, seed = ctx.args
-        if torch.is_grad_enabled():  # create_graph
-            if drop_p > 0.0:
-                raise NotImplementedError("second-order attention with alpha_drop > 0 (every MD17 config has alpha_drop = 0)")
-            gl, gv = so.vjp(lambda u, v: so.attn_aggregate(u, v, graph, H, layout), [logit, value], dout)
-            return gl, gv, None, None, None, None, None
+        if torch.is_grad_enabled():  # create_graph (the dropout mask is replayed from the seed)
+            dlogit, dvalue = _AttnAggregateBwd.apply(logit, value, dout, alpha, graph, H, layout, drop_p, seed)
+            return dlogit, dvalue, None, None, None, None, None
         dout = _c(dout)
         _chk(dout)
         dvalue = torch.empty_like(value)
@@ -1290,6 +1564,36 @@ class _AttnAggregate(Function):
         call("eqf_attn_aggregate_bwd", _p(alpha), _p(value), _p(graph.row_ptr), _p(dout), _p(dvalue), _p(dlogit),
              graph.N, H, layout.c_ref, drop_p, seed, _stream())
         return dlogit, dvalue, None, None, None, None, None
+
+
+class _AttnAggregateBwd(Function):
+    """(d_logit, d_value) of the per-destination softmax + aggregation as a differentiable op of (logit, value, d_out);
+    `alpha` is the softmax saved by the forward (its dependence on `logit` is accounted for in eqf_attn_aggregate_bwd2)."""
+
+    @staticmethod
+    def forward(ctx, logit, value, dout, alpha, graph, H, layout, drop_p, seed):
+        dout = _c(dout)
+        _chk(dout)
+        dvalue = torch.empty_like(value)
+        dlogit = torch.empty_like(alpha)
+        call("eqf_attn_aggregate_bwd", _p(alpha), _p(value), _p(graph.row_ptr), _p(dout), _p(dvalue), _p(dlogit),
+             graph.N, H, layout.c_ref, drop_p, seed, _stream())
+        ctx.save_for_backward(alpha, value, dout)
+        ctx.args = (graph, H, layout, drop_p, seed)
+        return dlogit, dvalue
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, cl, cv):
+        alpha, value, dout = ctx.saved_tensors
+        graph, H, layout, drop_p, seed = ctx.args
+        cl = _c(cl) if cl is not None else None
+        cv = _c(cv) if cv is not None else None
+        _chk(cl, cv)
+        g_logit, g_value, g_dout = torch.empty_like(alpha), torch.empty_like(value), torch.empty_like(dout)
+        call("eqf_attn_aggregate_bwd2", _p(alpha), _p(value), _p(graph.row_ptr), _p(dout), _p(cv), _p(cl), _p(g_logit),
+             _p(g_value), _p(g_dout), graph.N, H, layout.c_ref, drop_p, seed, _stream())
+        return g_logit, g_value, g_dout, None, None, None, None, None, None
 
 
 def attn_aggregate(logit, value, graph, H, layout, drop_p=0.0, seed=0):

@@ -336,6 +336,47 @@ int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* ro
                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Second-derivative entry points (MD17 force-loss training).  The reference takes forces with
+ * create_graph=True and back-propagates a loss on them [ref: nets/graph_attention_transformer_md17.py:
+ * 318-325, main_md17.py:384-390], so autograd differentiates the first backward pass.  For an
+ * operator whose first-order backward wrote dx = J^T dy, each *_bwd2 takes the cotangent c of dx and
+ * returns the gradient of Phi = <c, dx> wrt the operator's input(s), parameters (ACCUMULATED) and dy.
+ * The multilinear operators (linears, fused SeparableFCTP, gathers, coupling) need no extra entry
+ * points: their second-order terms are their first-order kernels with one argument substituted.
+ * ------------------------------------------------------------------------------------------- */
+int eqf_silu_bwd2(const float* x, const float* dy, const float* c, float* g_x, float* g_dy, long n, float c0,
+                  void* stream);
+/* c, g_in: [rows, S+G+dim(gated)]; d_out, g_dout: [rows, S+dim(gated)] */
+int eqf_gate_bwd2(const float* in, const float* d_out, const float* c, float* g_in, float* g_dout, int rows, int S,
+                  const eqf_irreps* gated, float c_silu, float c_sig, void* stream);
+/* g_gamma[C], g_beta[C] ACCUMULATED */
+int eqf_lnsilu_bwd2(const float* x, const float* gamma, const float* beta, const float* dy, const float* c,
+                    float* g_x, float* g_gamma, float* g_beta, float* g_dy, int rows, int C, float eps, void* stream);
+/* g_weight[num_irreps] ACCUMULATED (the bias does not enter dx) */
+int eqf_layernorm_bwd2(const float* x, const float* weight, const float* dy, const float* c, float* g_x,
+                       float* g_weight, float* g_dy, int rows, const eqf_irreps* irreps, float eps, void* stream);
+/* ca: cotangent of da [E, H*Kh]; g_alpha_dot[H*Kh] ACCUMULATED */
+int eqf_alpha_bwd2(const float* a, const float* alpha_dot, const float* d_logit, const float* ca, float* g_a,
+                   float* g_alpha_dot, float* g_dlogit, int E, int H, int Kh, float c, void* stream);
+/* c_value [E,D] / c_logit [E,H]: cotangents of d_value / d_logit (either may be NULL = zero); the dropout mask is
+ * the one of the forward (same seed).  g_logit[E,H], g_value[E,D], g_dout[N,D] written. */
+int eqf_attn_aggregate_bwd2(const float* alpha, const float* value, const int* row_ptr, const float* d_out,
+                            const float* c_value, const float* c_logit, float* g_logit, float* g_value,
+                            float* g_dout, int N, int H, const eqf_irreps* irreps, float drop_p,
+                            unsigned long long seed, void* stream);
+/* c_len [E]: cotangent of d_len; g_len[E], g_dout[E,R] written */
+int eqf_rbf_expnorm_bwd2(const float* len, const float* d_out, const float* c_len, int E, int R, const float* means,
+                         const float* betas, float alpha, float cutoff, float* g_len, float* g_dout, void* stream);
+/* as above for the Gaussian basis; g_mean[R], g_std[R], g_weight[1], g_bias[1] ACCUMULATED */
+int eqf_rbf_gaussian_bwd2(const float* len, const float* d_out, const float* c_len, int E, int R, const float* mean,
+                          const float* std, const float* weight, const float* bias, float cutoff, float* g_len,
+                          float* g_dout, float* g_mean, float* g_std, float* g_weight, float* g_bias, void* stream);
+/* c_vec [E,3]: cotangent of d_vec.  g_vec[E,3] written; g_dsh[E,(lmax+1)^2] and g_dlen[E] written if non-NULL;
+ * d_sh / d_len may be NULL exactly as in eqf_edge_geom_bwd. */
+int eqf_edge_geom_bwd2(const float* vec, const float* d_sh, const float* d_len, const float* c_vec, int E, int lmax,
+                       float* g_vec, float* g_dsh, float* g_dlen, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart; used by bench.py for the roofline line)
  * ------------------------------------------------------------------------------------------- */
 

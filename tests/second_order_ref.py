@@ -1,18 +1,13 @@
-"""Second-order support (MD17 force-loss training: `torch.autograd.grad(energy, pos, create_graph=True)` followed by
-`loss.backward()`, nets/graph_attention_transformer_md17.py:318-325 and main_md17.py:384-390 of the reference).
+"""Reference restatements for the second-derivative HIP kernels (TEST INFRASTRUCTURE, not product code).
 
-The first-order path (forward, backward, forces) is hand-written HIP everywhere.  A *differentiable* backward is only
-needed when the backward itself runs with `create_graph=True`; then (and only then)
-
-  * the multilinear ops (fused SeparableFCTP, per-degree / dense linears, gather / segment sums, coupling) use
-    `ops._*Backward` Functions whose own backward calls the SAME first-order HIP kernels with one argument substituted:
-    for Phi multilinear, sum_a <c_a, dPhi/da> = sum_a Phi(..., a <- c_a, ...), so every second-order term is a first-order
-    kernel evaluated at substituted arguments -- no new kernels;
-  * the eight non-linear ops (equivariant layer norm, gate, SiLU, LayerNorm+SiLU, SmoothLeakyReLU logits, segment
-    softmax + aggregation, exp-normal radial basis, edge geometry / spherical harmonics) recompute their forward with
-    the element-wise GPU tensor ops below (channel-fastest layout) and let autograd differentiate that twice.  This
-    is the one place where ATen element-wise kernels sit on the edge path; dedicated HIP second-derivative kernels are
-    the round-2 replacement.  Nothing here is used by forward passes, first-order training or force evaluation.
+MD17 force-loss training (`torch.autograd.grad(energy, pos, create_graph=True)` followed by `loss.backward()`,
+nets/graph_attention_transformer_md17.py:318-325 and main_md17.py:384-390 of the reference) differentiates the backward
+pass.  The product does that with hand-written HIP kernels (equiformer_amd/csrc/second.hip, `eqf_*_bwd2`).  The
+functions below restate the forward of the eight non-linear operators with plain torch ops in the channel-fastest
+layout, so that autograd can differentiate them twice: tests/test_second_order_restatements.py pins them against the
+oracle modules on the CPU (values, gradients, second derivatives), and tests/test_gpu_second_order.py checks every
+`eqf_*_bwd2` kernel against their double backward in fp64.  In round 1 this file lived in the product package and WAS
+the create_graph path; nothing under equiformer_amd/ imports it any more.
 
 Formulas restate the same reference code as the HIP kernels they shadow (cited per function).
 """

@@ -109,7 +109,7 @@ def test_hip_reproduces_qm9_fixture():
     g = torch.autograd.grad(loss, [m.blocks[0].ga.sep_act.lin.tp.weight, m.blocks[1].ga.alpha_dot,
                                    m.blocks[0].ga.sep_act.dtp_rad.net[0].weight, m.rbf.mean])
     for got, key in zip(g, ("g_sep_act_lin", "g_alpha_dot", "g_rad0", "g_rbf_mean")):
-        assert _rel(got, outs[key]) < 5e-4, key  # gradients: looser (sums of many fp32 terms), still fp32-class
+        assert _rel(got, outs[key]) < 1e-4, key
 
 
 @pytest.mark.gpu
@@ -125,7 +125,7 @@ def test_hip_reproduces_linear_message_fixture():
     g = torch.autograd.grad(loss, [m.blocks[0].ga.sep.lin.tp.weight, m.blocks[1].ga.alpha_dot,
                                    m.blocks[0].ga.sep.lin.bias[0]])
     for got, key in zip(g, ("g_sep_lin", "g_alpha_dot", "g_sep_bias")):
-        assert _rel(got, outs[key]) < 5e-4, key
+        assert _rel(got, outs[key]) < 1e-4, key
 
 
 @pytest.mark.gpu

@@ -1,11 +1,15 @@
 """The differentiable tensor-op restatements that the second-order (create_graph) path of the HIP operators uses
-(equiformer_amd/second_order.py) are plain torch code in the channel-fastest layout, so they can be pinned on the CPU:
+(tests/second_order_ref.py) are plain torch code in the channel-fastest layout, so they can be pinned on the CPU:
 values, first derivatives and second derivatives (vjp of the vjp) against the oracle modules (e3nn layout)."""
 from types import SimpleNamespace
 
 import torch
 
-from equiformer_amd import second_order as so
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import second_order_ref as so  # noqa: E402
 from equiformer_amd import so3
 from equiformer_amd.layout import RowLayout
 from oracle import e3
