@@ -41,7 +41,9 @@ def parse():
                     help="kernel-name substring timed with HIP events for the roofline line ('' = every matrix-core "
                          "kernel; the one with the largest total time is reported)")
     ap.add_argument("--cpu-molecules", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--no-cpu-full-batch", dest="cpu_full_batch", action="store_false",
+                    help="skip the like-for-like CPU run at the bench batch (3 steps of ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -55,35 +57,54 @@ def make_optimizer(model, lr=5e-4, weight_decay=5e-3, reducer=None):
 
 
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference, plain torch fp32) doing the same train step on the host cores,
-    on a bounded sample of the workload (same molecule shape, smaller batch)."""
+    """The oracle (CPU restatement of the reference, plain torch fp32) doing the same train step on the host cores
+    (SURVEY.md section 8d): at the bench's own batch (128 molecules: like for like, few steps -- one step is ~15 s) and
+    at the reference's CPU plumbing batch (8 molecules: 3 warm-up + 10 timed steps); medians.  `value` is the
+    like-for-like figure."""
+    import statistics
     from equiformer_amd.synthetic import qm9_like_batch
     from oracle import nets as onets
-    # the oracle's tensors are small (8 molecules): more than ~16 threads only adds synchronisation cost
     cores = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = onets.graph_attention_transformer_nonlinear_l2("5x0e", 5.0).train()
     opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=5e-3)
-    d = qm9_like_batch(args.cpu_molecules, args.atoms, side=args.side, seed=0)
 
-    def step():
-        opt.zero_grad()
-        loss = (model(None, d["pos"], d["batch"], d["z"]).squeeze() - d["y"]).abs().mean()
-        loss.backward()
-        opt.step()
+    def run(molecules, warm, steps, budget_s):
+        d = qm9_like_batch(molecules, args.atoms, side=args.side, seed=0)
 
-    step()  # warm-up
-    t0 = time.perf_counter()
-    done = 0
-    while done < args.cpu_steps and (done == 0 or time.perf_counter() - t0 < 30.0):
-        step()
-        done += 1
-    dt = (time.perf_counter() - t0) / done
-    args.cpu_steps = done
-    return {"value": args.cpu_molecules / dt, "unit": "molecules/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps of %d molecules x %d atoms (oracle, torch fp32 CPU, %d threads), %.2f s/step"
-                      % (args.cpu_steps, args.cpu_molecules, args.atoms, cores, dt)}
+        def step():
+            opt.zero_grad()
+            loss = (model(None, d["pos"], d["batch"], d["z"]).squeeze() - d["y"]).abs().mean()
+            loss.backward()
+            opt.step()
+
+        for _ in range(warm):
+            step()
+        ts, t_begin = [], time.perf_counter()
+        while len(ts) < steps and (not ts or time.perf_counter() - t_begin < budget_s):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), len(ts)
+
+    small_dt, small_n = run(args.cpu_molecules, 3, args.cpu_steps, 30.0)
+    out = {"unit": "molecules/s", "cores": cores, "kind": "port",
+           "batch_%d" % args.cpu_molecules: {"value": args.cpu_molecules / small_dt, "s_per_step": small_dt,
+                                             "timed_steps": small_n, "warmup_steps": 3}}
+    big = args.batch if args.cpu_full_batch else 0
+    if big:
+        big_dt, big_n = run(big, 1, 3, 60.0)
+        out["batch_%d" % big] = {"value": big / big_dt, "s_per_step": big_dt, "timed_steps": big_n, "warmup_steps": 1}
+        out["value"] = big / big_dt
+        out["sample"] = ("median of %d train steps of %d molecules x %d atoms (the bench batch; oracle = CPU restatement of "
+                         "the reference, torch fp32, %d threads), %.2f s/step; batch %d: median of %d steps, %.3f s/step"
+                         % (big_n, big, args.atoms, cores, big_dt, args.cpu_molecules, small_n, small_dt))
+    else:
+        out["value"] = args.cpu_molecules / small_dt
+        out["sample"] = ("median of %d train steps of %d molecules x %d atoms (oracle, torch fp32 CPU, %d threads), "
+                         "%.3f s/step" % (small_n, args.cpu_molecules, args.atoms, cores, small_dt))
+    return out
 
 
 def main():
@@ -172,9 +193,8 @@ def main():
                 "global_batch": args.batch * world, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
                 "edges_per_molecule": n_edges / args.batch, "parallelism": "dp%d" % world,
                 "final_loss": float(loss.item()),
-                "arithmetic": "fp32 storage and accumulation everywhere; exact-fp32 MFMA in the backward kernels and "
-                              "GEMMs; the forward SeparableFCTP contraction splits each fp32 operand exactly into 3 bf16 "
-                              "terms and sums six bf16-MFMA products (error 3e-7 of the result scale = the fp32 GEMM's)",
+                "arithmetic": "fp32 storage and accumulation everywhere; every contraction on the exact-fp32 MFMA "
+                              "(v_mfma_f32_32x32x2_f32 / 16x16x4_f32: bit-equal to an fmaf chain)",
             },
         }
         rec = None
@@ -185,15 +205,25 @@ def main():
             name, r = rec
             avg_ms = r["total_ms"] / r["launches"]
             tflops = r["flops"] / r["total_ms"] / 1e9
-            traffic = None
+            # HBM bytes per launch from the PMC passes over this same command (tools/gpu_profile.sh -> tools/pmc_bench.py);
+            # only reported when they were taken on the build that is running now
+            traffic, traffic_note = None, "no PMC measurement for this build (profiles/pmc_dominant.json)"
             pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+                    from equiformer_amd.build import source_hash
+                    rec_pmc = json.load(open(pmc))
+                    if rec_pmc.get("build") == source_hash():
+                        traffic = rec_pmc.get(name, {}).get("hbm_bytes_per_launch")
+                        traffic_note = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE over bench.py, build " + rec_pmc["build"]
+                    else:
+                        traffic_note = "profiles/pmc_dominant.json belongs to build %s, running %s" % (
+                            rec_pmc.get("build"), source_hash())
+                except Exception as exc:  # a malformed file must not take the bench line down
+                    traffic_note = "profiles/pmc_dominant.json unreadable: %r" % (exc,)
             out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel": name,
+                               "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+                               "kernel": name,
                                "launches": r["launches"], "avg_launch_ms": avg_ms,
                                "flops_per_launch": r["flops"] / r["launches"],
                                "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],

@@ -16,6 +16,19 @@ SOURCES = ["gemm.hip", "sfc.hip", "rowops.hip", "edge.hip", "graph.hip", "second
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
+def source_hash():
+    """sha256 over the HIP sources + the public header: identifies the build a measurement (profiles/pmc_dominant.json)
+    belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(HERE, "..", "include", "equiformer_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

@@ -126,13 +126,20 @@ class FlatAdamW(torch.optim.Optimizer):
             if g["lr"] != g0["lr"] or g["betas"] != g0["betas"] or g["eps"] != g0["eps"]:
                 raise ValueError("FlatAdamW: lr / betas / eps must agree across parameter groups")
         # gradients -> flat buffer (already there when the reducer re-pointed .grad at its slices)
-        src, dst, zero = [], [], []
-        for p, v in zip(self._params, self._gviews):
+        src, dst, zero, skipped = [], [], [], []
+        off = 0
+        for p, v, k in zip(self._params, self._gviews, self.sizes):
             if p.grad is None:
                 zero.append(v)
+                skipped.append((off, k))
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
+            off += k
+        # torch.optim.AdamW leaves a parameter without a gradient untouched (no decay, no moment decay); the fused kernel
+        # updates the whole flat buffer, so such slices (rare: a parameter unused this step) are saved and put back
+        saved = [(o, k, self.flat_p[o:o + k].clone(), self.flat_m[o:o + k].clone(), self.flat_v[o:o + k].clone(),
+                  None if self.flat_ema is None else self.flat_ema[o:o + k].clone()) for o, k in skipped]
         if zero:
             torch._foreach_zero_(zero)
         if src:
@@ -146,6 +153,12 @@ class FlatAdamW(torch.optim.Optimizer):
         call("eqf_adamw_step", _P(self.flat_p), _P(self.flat_g), _P(self.flat_m), _P(self.flat_v), _P(self.flat_wd),
              _P(self.flat_ema), _P(self._sumsq) if clip else None, self.n, float(g0["lr"]), float(b1), float(b2),
              float(g0["eps"]), self._step, float(self.clip_grad or 0.0), float(self.ema_decay or 0.0), st)
+        for o, k, sp, sm, sv, se in saved:
+            self.flat_p[o:o + k].copy_(sp)
+            self.flat_m[o:o + k].copy_(sm)
+            self.flat_v[o:o + k].copy_(sv)
+            if se is not None:  # the EMA still follows the (unchanged) weights
+                self.flat_ema[o:o + k].copy_(se.mul_(self.ema_decay).add_(sp, alpha=1.0 - self.ema_decay))
         for p in self._params:
             self.state[p]["step"] = self._step
         return loss

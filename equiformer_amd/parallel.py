@@ -1,31 +1,61 @@
-"""Data parallelism over molecules: one process per GPU, one flat fp32 gradient buffer, ONE all-reduce per step.
+"""Data parallelism over molecules: one process per GPU, one flat fp32 gradient buffer, two collectives per step.
 
 The reference wraps the model in DistributedDataParallel over NCCL (main_qm9.py:178-179; oc20/trainer/
-base_trainer_v2.py:376-384) with torch's default 25 MB buckets.  The whole Equiformer gradient is 14-36 MB and xGMI
-is point-to-point (7 links x ~153 GB/s per GPU), so a ring of several bucketed collectives is latency bound; one
-flat buffer = a single RCCL all-reduce per step (backend "nccl" is RCCL on ROCm; "gloo" on CPU for tests).
-Molecules never interact (edges stay inside a molecule), so no other collective exists on the data path.
+base_trainer_v2.py:376-384) with torch's default 25 MB buckets and shards the data set with a DistributedSampler
+(main_qm9.py:204-210) or, for OC20, a sampler that balances the shards by atom count
+(oc20/trainer/base_trainer_oc20.py:238-256).  The whole Equiformer gradient is 14-36 MB and xGMI is point-to-point
+(7 links x ~153 GB/s per GPU), so a ring of many bucketed collectives is latency bound.  Here:
+
+  * every parameter's gradient lives in ONE flat buffer (`FlatGradAllReduce.flat`, shared with the fused optimizer),
+    laid out in forward order and cut once into a HEAD part (embeddings + first blocks) and a TAIL part (last blocks +
+    output head);
+  * the TAIL part -- whose gradients are complete first, backward runs the layers in reverse -- is all-reduced
+    asynchronously from a gradient hook in the middle of backward, so that its RCCL collective overlaps the rest of
+    backward; the HEAD part follows when backward is done (`reduce()`);
+  * molecules never interact (edges stay inside a molecule), so no other collective exists on the data path;
+  * `shard_balanced` splits a batch over the ranks with near-equal sums of a per-molecule cost (edge count): the only
+    scaling hazard of this path is the imbalance of the variable-size graphs.
+
+Backend "nccl" is RCCL on ROCm; "gloo" on CPU for the tests.
 """
 import torch
 import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    """Owns a flat buffer aliased by every parameter's .grad; `reduce()` averages it across ranks in one collective."""
+    """Owns a flat buffer aliased by every parameter's .grad after `reduce()`; averages it across the ranks.
 
-    def __init__(self, module, process_group=None):
+    overlap: fraction of the gradient bytes (counted from the END of the forward order) that is all-reduced from a
+    hook during backward; 0 disables the hook (one collective in `reduce()`)."""
+
+    def __init__(self, module, process_group=None, overlap=0.5):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.group = process_group
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
-        self.views = []
+        self.views, self.offsets = [], []
         for p in self.params:
             v = self.flat[off:off + p.numel()].view_as(p)
             self.views.append(v)
+            self.offsets.append(off)
             off += p.numel()
+        # cut: parameters [k, end) form the tail bucket; the trigger is the LAST parameter of the head bucket whose
+        # gradient appears once backward has passed the cut (autograd runs ready nodes latest-created first, so by
+        # then every node of the later layers, side branches included, has run)
+        self.split = len(self.params)
+        self._handle = None
+        self._pending = None
+        self._tail_done = False
+        if overlap > 0 and len(self.params) > 1:
+            want = n * (1.0 - overlap)
+            k = next((i for i, o in enumerate(self.offsets) if o >= want), len(self.params))
+            k = min(max(k, 1), len(self.params) - 1)
+            self.split = k
+            self._handle = self.params[k - 1].register_post_accumulate_grad_hook(self._on_trigger)
 
+    # ---------------------------------------------------------------------------------------------------------------
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -36,24 +66,50 @@ class FlatGradAllReduce:
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.group)
 
-    def reduce(self):
-        """Pack every .grad into the flat buffer (multi-tensor copy: a handful of launches, not one per parameter),
-        all-reduce(mean) it in ONE collective, and re-point each .grad at its slice of the buffer (no copy back).
-        Call after backward()."""
-        have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
-        missing = [v for p, v in zip(self.params, self.views) if p.grad is None]
+    def _pack(self, lo, hi):
+        """gradients of parameters [lo, hi) -> their slices of the flat buffer (multi-tensor copy: a handful of launches)"""
+        have = [(p, v) for p, v in zip(self.params[lo:hi], self.views[lo:hi])
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        missing = [v for p, v in zip(self.params[lo:hi], self.views[lo:hi]) if p.grad is None]
         if missing:
             torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
+
+    def _all_reduce(self, buf, async_op):
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":  # RCCL averages in the collective itself
+            return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), False
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), True
+
+    def _on_trigger(self, _param):
+        """Runs inside backward once the gradient of the last head-bucket parameter has been accumulated."""
+        if self._tail_done or self.world_size() == 1:
+            return
+        if any(p.grad is None for p in self.params[self.split:]):
+            return  # a tail gradient is not there yet (unusual graph): fall back to the synchronous path in reduce()
+        self._pack(self.split, len(self.params))
+        tail = self.flat[self.offsets[self.split]:]
+        self._pending = self._all_reduce(tail, async_op=True)
+        self._tail_done = True
+
+    def reduce(self):
+        """Call after backward(): finishes the average of the flat gradient (waits for the collective launched during
+        backward, reduces the rest) and re-points each .grad at its slice of the buffer (no copy back)."""
         ws = self.world_size()
+        n_head = self.split if self._tail_done else len(self.params)
+        self._pack(0, n_head)
         if ws > 1:
-            backend = dist.get_backend(self.group)
-            if backend == "nccl":  # RCCL averages in the collective itself
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-                self.flat.div_(ws)
+            head = self.flat[:self.offsets[self.split]] if self._tail_done else self.flat
+            _, need_div_head = self._all_reduce(head, async_op=False)
+            if need_div_head:
+                head.div_(ws)
+            if self._pending is not None:
+                work, need_div = self._pending
+                work.wait()
+                if need_div:
+                    self.flat[self.offsets[self.split]:].div_(ws)
+        self._pending, self._tail_done = None, False
         for p, v in zip(self.params, self.views):
             p.grad = v
         return self.flat
@@ -65,3 +121,28 @@ def shard_molecules(num_molecules, rank, world_size):
     rem = num_molecules % world_size
     start = rank * per + min(rank, rem)
     return range(start, start + per + (1 if rank < rem else 0))
+
+
+def shard_balanced(costs, world_size):
+    """Split molecules over `world_size` ranks with near-equal total cost (cost = edge count of the molecule: the edge
+    pass is >95 % of the work).  Greedy longest-processing-time assignment with equal molecule counts per rank (+-1),
+    so every rank also keeps the same per-step batch size.  Returns a list of index lists (ascending inside a rank).
+    [ref: the role of BalancedBatchSampler, oc20/trainer/base_trainer_oc20.py:238-256]"""
+    costs = [float(c) for c in costs]
+    n = len(costs)
+    cap = [n // world_size + (1 if r < n % world_size else 0) for r in range(world_size)]
+    load = [0.0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in sorted(range(n), key=lambda i: -costs[i]):
+        r = min((r for r in range(world_size) if len(out[r]) < cap[r]), key=lambda r: load[r])
+        out[r].append(i)
+        load[r] += costs[i]
+    return [sorted(ix) for ix in out]
+
+
+def molecule_edge_counts(pos, batch, r, max_num_neighbors=1000):
+    """Directed edges per molecule of the radius graph (device tensor, int64): the cost `shard_balanced` wants."""
+    from .graph import EdgeGraph
+    g = EdgeGraph.from_radius(pos, batch, r, max_num_neighbors)
+    deg = (g.row_ptr[1:] - g.row_ptr[:-1]).to(torch.int64)
+    return torch.zeros(g.num_graphs, dtype=torch.int64, device=pos.device).index_add_(0, g.batch.to(torch.int64), deg)

@@ -1,0 +1,110 @@
+"""The N > 1 path with the HIP model: two ranks (gloo, both on cuda:0 -- the GPU boxes of the test tier have one GPU)
+run the sharded train step through FlatGradAllReduce (tail bucket reduced from the backward hook) + FlatAdamW; the
+averaged gradient must equal the full-batch gradient of a single process and the replicas must stay identical.
+[ref: DDP + DistributedSampler, main_qm9.py:178-179,204-210]"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(dev):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as mg
+    from weights import fill_deterministic
+    from equiformer_amd.nets.graph_attention_transformer import GraphAttentionTransformer
+    m = GraphAttentionTransformer(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **dict(mg.SMALL_L2, alpha_drop=0.0))
+    return fill_deterministic(m, 21).to(dev).train()
+
+
+def _loss(model, d, idx, dev):
+    n = d["pos"].shape[0] // d["y"].shape[0]
+    sel = torch.cat([torch.arange(i * n, (i + 1) * n) for i in idx])
+    batch = torch.repeat_interleave(torch.arange(len(idx)), n)
+    y = model(None, d["pos"][sel].to(dev), batch.to(dev), d["z"][sel].to(dev)).squeeze(-1)
+    return (y - d["y"][list(idx)].to(dev)).abs().mean()
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from equiformer_amd.optim import FlatAdamW, add_weight_decay
+    from equiformer_amd.parallel import FlatGradAllReduce, shard_molecules
+    from equiformer_amd.synthetic import qm9_like_batch
+    model = _model(dev)
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.25)
+    red = FlatGradAllReduce(model)
+    red.broadcast_parameters()
+    opt = FlatAdamW(add_weight_decay(model, 5e-3, model.no_weight_decay()), lr=1e-3, reducer=red)
+    d = qm9_like_batch(4, 10, side=5.0, seed=5)
+    idx = shard_molecules(4, rank, world)
+    opt.zero_grad(set_to_none=True)
+    _loss(model, d, idx, dev).backward()
+    overlapped = bool(red._tail_done)
+    flat = red.reduce().clone().cpu()
+    opt.step()
+    torch.cuda.synchronize()
+    checksum = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double().sum().cpu()
+    torch.save({"flat": flat, "checksum": checksum, "overlapped": overlapped}, os.path.join(out, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_hip_model_flat_allreduce(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert r0["overlapped"] and r1["overlapped"]
+    assert torch.equal(r0["flat"], r1["flat"]), "ranks disagree on the reduced gradient"
+    assert r0["checksum"].item() == r1["checksum"].item(), "replicas diverged after the optimizer step"
+    sys.path.insert(0, ROOT)
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    d = qm9_like_batch(4, 10, side=5.0, seed=5)
+    _loss(model, d, range(4), dev).backward()
+    full = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                      for p in model.parameters() if p.requires_grad]).cpu()
+    err = ((full - r0["flat"]).abs().max() / full.abs().max()).item()
+    assert err < 2e-5, err
+
+
+def test_molecule_edge_counts_and_balanced_shards():
+    from equiformer_amd.graph import EdgeGraph
+    from equiformer_amd.parallel import molecule_edge_counts, shard_balanced
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = torch.device("cuda:0")
+    parts = [qm9_like_batch(1, n, side=4.0 + 0.2 * n, seed=n) for n in (6, 18, 9, 14, 18, 7, 11, 16)]
+    pos = torch.cat([p["pos"] for p in parts]).to(dev)
+    batch = torch.cat([torch.full((p["pos"].shape[0],), i) for i, p in enumerate(parts)]).to(dev)
+    counts = molecule_edge_counts(pos, batch, 5.0)
+    g = EdgeGraph.from_radius(pos, batch, 5.0)
+    assert int(counts.sum()) == g.E and counts.shape[0] == 8
+    shards = shard_balanced(counts.tolist(), 2)
+    loads = [sum(int(counts[i]) for i in s) for s in shards]
+    assert abs(loads[0] - loads[1]) <= int(counts.max())

@@ -189,3 +189,34 @@ def test_flat_adamw_trains_model_like_torch_adamw():
         ya = a(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"])
         yb = b(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"])
     assert (ya - yb).abs().max() <= 1e-4 * max(1.0, float(ya.abs().max()))
+
+
+@pytest.mark.gpu
+def test_flat_adamw_leaves_gradless_parameters_untouched():
+    """torch.optim.AdamW skips a parameter whose .grad is None (no weight decay, no moment decay); the fused flat-buffer
+    step must do the same, EMA included (the EMA still follows the unchanged weight)."""
+    from equiformer_amd.optim import FlatAdamW
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    ta = [torch.randn(n, generator=g).to(dev).requires_grad_(True) for n in (33, 128, 7)]
+    tb = [t.detach().clone().requires_grad_(True) for t in ta]
+    oa = torch.optim.AdamW(ta, lr=1e-2, weight_decay=0.1)
+    ob = FlatAdamW(tb, lr=1e-2, weight_decay=0.1, ema_decay=0.9)
+    ema = [t.detach().clone() for t in tb]
+    for step in range(4):
+        for i, (pa, pb) in enumerate(zip(ta, tb)):
+            if i == 1 and step in (1, 2):  # parameter 1 receives no gradient in steps 1 and 2
+                pa.grad = pb.grad = None
+            else:
+                gr = torch.randn(pa.shape, generator=g).to(dev)
+                pa.grad, pb.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+        ema = [0.9 * e + 0.1 * p.detach() for e, p in zip(ema, tb)]
+    for pa, pb in zip(ta, tb):
+        assert (pa.detach() - pb.detach()).abs().max() <= 2e-6 * max(1.0, float(pa.detach().abs().max()))
+    off = 0
+    for e, p in zip(ema, tb):
+        got = ob.flat_ema[off:off + p.numel()]
+        assert (got - e).abs().max() <= 2e-6
+        off += p.numel()

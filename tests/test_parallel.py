@@ -60,10 +60,12 @@ def _worker(rank, world, port, out):
     opt = torch.optim.SGD(model.parameters(), lr=1e-2)
     opt.zero_grad()
     _loss(model, d, idx).backward()
+    overlapped = bool(red._tail_done)  # the tail bucket's collective was launched from the hook, during backward
     flat = red.reduce().clone()
     opt.step()
     checksum = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double().sum()
-    torch.save({"flat": flat, "checksum": checksum, "idx": list(idx)}, os.path.join(out, "rank%d.pt" % rank))
+    torch.save({"flat": flat, "checksum": checksum, "idx": list(idx), "overlapped": overlapped, "split": red.split,
+                "nparams": len(red.params)}, os.path.join(out, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,6 +76,8 @@ def test_two_rank_gloo_flat_allreduce_matches_full_batch(tmp_path):
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
     assert r0["idx"] == [0, 1] and r1["idx"] == [2, 3]
+    assert r0["overlapped"] and r1["overlapped"], "the tail bucket must be reduced from the backward hook"
+    assert 0 < r0["split"] < r0["nparams"]
     assert torch.equal(r0["flat"], r1["flat"]), "ranks disagree on the reduced gradient"
     assert abs(r0["checksum"].item() - r1["checksum"].item()) == 0.0, "replicas diverged after the step"
     # single-process reference: mean over the 4 molecules == mean of the two per-shard means (equal shard sizes)
@@ -96,3 +100,22 @@ def test_shard_molecules_partitions_every_molecule_once():
             assert got == list(range(n))
             sizes = [len(shard_molecules(n, r, w)) for r in range(w)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_balanced_equalises_edge_counts():
+    from equiformer_amd.parallel import shard_balanced
+    g = torch.Generator().manual_seed(0)
+    costs = (torch.randint(50, 2800, (257,), generator=g)).tolist()  # OC20-like spread of edge counts
+    for w in (1, 2, 4, 8):
+        shards = shard_balanced(costs, w)
+        assert sorted(i for s in shards for i in s) == list(range(len(costs)))
+        sizes = [len(s) for s in shards]
+        assert max(sizes) - min(sizes) <= 1
+        loads = [sum(costs[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(costs), (w, loads)
+        # contiguous sharding of the same list is (much) worse once the costs are sorted, the adversarial order
+        srt = sorted(costs)
+        per = len(srt) // w
+        naive = [sum(srt[r * per:(r + 1) * per]) for r in range(w)]
+        bal = [sum(srt[i] for i in s) for s in shard_balanced(srt, w)]
+        assert max(bal) - min(bal) <= max(naive) - min(naive)
