@@ -87,6 +87,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if ema_decay is not None:
             self.flat_ema = self.flat_p.clone()
         self._step = 0
+        self._lag = [0] * len(ps)  # steps a parameter missed because it had no gradient (torch keeps a per-parameter count)
 
     @staticmethod
     def _check_params(ps):
@@ -126,20 +127,23 @@ class FlatAdamW(torch.optim.Optimizer):
             if g["lr"] != g0["lr"] or g["betas"] != g0["betas"] or g["eps"] != g0["eps"]:
                 raise ValueError("FlatAdamW: lr / betas / eps must agree across parameter groups")
         # gradients -> flat buffer (already there when the reducer re-pointed .grad at its slices)
-        src, dst, zero, skipped = [], [], [], []
+        src, dst, zero, slow = [], [], [], []
         off = 0
-        for p, v, k in zip(self._params, self._gviews, self.sizes):
+        for i, (p, v, k) in enumerate(zip(self._params, self._gviews, self.sizes)):
             if p.grad is None:
                 zero.append(v)
-                skipped.append((off, k))
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
+            if p.grad is None or self._lag[i] > 0:
+                slow.append((i, off, k, p.grad is not None))
             off += k
-        # torch.optim.AdamW leaves a parameter without a gradient untouched (no decay, no moment decay); the fused kernel
-        # updates the whole flat buffer, so such slices (rare: a parameter unused this step) are saved and put back
-        saved = [(o, k, self.flat_p[o:o + k].clone(), self.flat_m[o:o + k].clone(), self.flat_v[o:o + k].clone(),
-                  None if self.flat_ema is None else self.flat_ema[o:o + k].clone()) for o, k in skipped]
+        # torch.optim.AdamW skips a parameter without a gradient entirely (no decay, no moment decay, its own step
+        # count is not advanced).  The fused kernel updates the whole flat buffer with ONE step count, so the (rare)
+        # parameters that are skipped now, or were skipped before and therefore lag behind the global count, are saved
+        # here and redone below with tensor ops on their slices.
+        saved = [(i, o, k, has, self.flat_p[o:o + k].clone(), self.flat_m[o:o + k].clone(), self.flat_v[o:o + k].clone(),
+                  None if self.flat_ema is None else self.flat_ema[o:o + k].clone()) for i, o, k, has in slow]
         if zero:
             torch._foreach_zero_(zero)
         if src:
@@ -150,17 +154,30 @@ class FlatAdamW(torch.optim.Optimizer):
             call("eqf_sumsq", _P(self.flat_g), self.n, _P(self._sumsq), st)
         self._step += 1
         b1, b2 = g0["betas"]
+        lr, eps = float(g0["lr"]), float(g0["eps"])
         call("eqf_adamw_step", _P(self.flat_p), _P(self.flat_g), _P(self.flat_m), _P(self.flat_v), _P(self.flat_wd),
-             _P(self.flat_ema), _P(self._sumsq) if clip else None, self.n, float(g0["lr"]), float(b1), float(b2),
-             float(g0["eps"]), self._step, float(self.clip_grad or 0.0), float(self.ema_decay or 0.0), st)
-        for o, k, sp, sm, sv, se in saved:
+             _P(self.flat_ema), _P(self._sumsq) if clip else None, self.n, lr, float(b1), float(b2), eps, self._step,
+             float(self.clip_grad or 0.0), float(self.ema_decay or 0.0), st)
+        for i, o, k, has, sp, sm, sv, se in saved:
+            if has:  # same arithmetic as the kernel, with this parameter's own step count
+                t = self._step - self._lag[i]
+                g = self.flat_g[o:o + k]
+                if clip:
+                    g = g * torch.clamp(self.clip_grad / (self._sumsq.sqrt() + 1e-6), max=1.0)
+                sp.mul_(1.0 - lr * self.flat_wd[o:o + k])
+                sm.mul_(b1).add_(g, alpha=1.0 - b1)
+                sv.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                denom = (sv.sqrt() / (1.0 - b2 ** t) ** 0.5).add_(eps)
+                sp.addcdiv_(sm, denom, value=-lr / (1.0 - b1 ** t))
+            else:
+                self._lag[i] += 1
             self.flat_p[o:o + k].copy_(sp)
             self.flat_m[o:o + k].copy_(sm)
             self.flat_v[o:o + k].copy_(sv)
-            if se is not None:  # the EMA still follows the (unchanged) weights
+            if se is not None:  # the EMA follows the weights, updated or not
                 self.flat_ema[o:o + k].copy_(se.mul_(self.ema_decay).add_(sp, alpha=1.0 - self.ema_decay))
-        for p in self._params:
-            self.state[p]["step"] = self._step
+        for i, p in enumerate(self._params):
+            self.state[p]["step"] = self._step - self._lag[i]
         return loss
 
     def load_state_dict(self, state_dict):
@@ -192,8 +209,10 @@ class FlatAdamW(torch.optim.Optimizer):
                 self.flat_wd[off:off + k].fill_(float(wd_of[id(p)]))
                 off += k
         self._step = step
-        for p in self._params:
-            self.state[p]["step"] = step
+        own = {id(p): int(state_dict["state"][i]["step"]) for p, i in zip(order, ids) if i in state_dict["state"]}
+        for i, p in enumerate(self._params):
+            self._lag[i] = step - own.get(id(p), step)  # parameters that missed steps keep their own (smaller) count
+            self.state[p]["step"] = step - self._lag[i]
 
     def grad_norm(self):
         """Global gradient norm of the last clipped step (device scalar, no sync)."""

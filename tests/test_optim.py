@@ -129,17 +129,20 @@ def test_flat_adamw_matches_oracle(clip, ema):
         for t, g in zip(tp, gs):
             t.grad = g.float().to(dev)
         if step == 3:
-            tp[3].grad = None  # a parameter without gradient counts as zero gradient
+            tp[3].grad = None  # torch.optim.AdamW leaves a parameter without gradient untouched (own step count too)
         opt.step()
         gn = [g.float().double().numpy() * (0.0 if (step == 3 and i == 3) else 1.0) for i, g in enumerate(gs)]
         coef = ooptim.clip_coef(gn, clip)[0] if clip else 1.0
         for i in range(len(p)):
-            p[i], m[i], v[i] = ooptim.adamw_step(p[i], gn[i] * coef, m[i], v[i], step, 5e-4, 0.9, 0.999, 1e-8, wds[i])
+            if not (step == 3 and i == 3):
+                own_step = step - (1 if (i == 3 and step > 3) else 0)
+                p[i], m[i], v[i] = ooptim.adamw_step(p[i], gn[i] * coef, m[i], v[i], own_step, 5e-4, 0.9, 0.999, 1e-8, wds[i])
             if ema:
                 e[i] = ooptim.ema_update(e[i], p[i], ema)
             assert np.abs(p[i] - tp[i].detach().double().cpu().numpy()).max() < 2e-6 * max(1.0, np.abs(p[i]).max())
     sd = opt.state_dict()
     assert sd["state"][0]["step"] == len(grads) and sd["state"][0]["exp_avg"].shape == ps0[0].shape
+    assert sd["state"][3]["step"] == len(grads) - (1 if len(grads) >= 3 else 0)
     assert np.abs(m[2] - opt.state[tp[2]]["exp_avg"].double().cpu().numpy()).max() < 1e-6
     if ema:
         class Holder(torch.nn.Module):
