@@ -398,6 +398,67 @@ __global__ __launch_bounds__(256) void rbf_expnorm_dlen_kernel(const float* __re
   if (lane == 0) d_len[e] = acc;
 }
 
+
+// ---- spherical Bessel basis with polynomial envelope (GemNet RadialBasis of ocpmodels 0.0.3, un-vendored dependency of
+// the reference: ocpmodels/models/gemnet/layers/radial_basis.py; call sites nets/graph_attention_transformer.py:26,
+// 786-788).  x = len / rc;  out[e,k] = env(x) sqrt(2 / rc^3) sin(f_k x) / x,  env = 1 + a x^5 + b x^6 + c x^7 for x < 1
+// (p = 5: a = -21, b = 35, c = -15), frequencies f_k trainable (initialised k pi).
+struct BesselEnv {
+  float e0, e1, e2;  // envelope value and its first two derivatives wrt x
+};
+__device__ __forceinline__ BesselEnv bessel_env(float x) {
+  BesselEnv r{0.f, 0.f, 0.f};
+  if (x < 1.f) {
+    const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x;
+    r.e0 = 1.f + x5 * (-21.f + x * (35.f - 15.f * x));
+    r.e1 = x4 * (-105.f + x * (210.f - 105.f * x));
+    r.e2 = x3 * (-420.f + x * (1050.f - 630.f * x));
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void rbf_bessel_fwd_kernel(const float* __restrict__ len, long total, int R,
+                                                             const float* __restrict__ freq, float inv_rc, float nc,
+                                                             float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long e = idx / R;
+  const int r = (int)(idx - e * R);
+  const float x = len[e] * inv_rc;
+  const BesselEnv ev = bessel_env(x);
+  out[idx] = ev.e0 * nc * sinf(freq[r] * x) / x;
+}
+
+// one wave per edge: d_len[e]; d_freq accumulated per block through LDS
+__global__ __launch_bounds__(256) void rbf_bessel_bwd_kernel(const float* __restrict__ len, const float* __restrict__ g,
+                                                             int E, int R, const float* __restrict__ freq, float inv_rc,
+                                                             float nc, float* __restrict__ d_len,
+                                                             float* __restrict__ d_freq, int EPB) {
+  extern __shared__ float red[];  // [R]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) red[r] = 0.f;
+  __syncthreads();
+  const int e0 = blockIdx.x * EPB, e1 = min(E, e0 + EPB);
+  for (int e = e0 + wave; e < e1; e += 4) {
+    const float x = len[e] * inv_rc;
+    const BesselEnv ev = bessel_env(x);
+    const float ix = 1.f / x;
+    float acc = 0.f;
+    for (int r = lane; r < R; r += 64) {
+      const float f = freq[r], sn = sinf(f * x), cs = cosf(f * x);
+      const float s0 = sn * ix, s1 = f * cs * ix - sn * ix * ix;
+      const float gv = g[(long)e * R + r];
+      acc += gv * nc * (ev.e1 * s0 + ev.e0 * s1);
+      if (d_freq) atomicAdd(&red[r], gv * nc * ev.e0 * cs);  // d/df [sin(f x) / x] = cos(f x)
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && d_len) d_len[e] = acc * inv_rc;
+  }
+  __syncthreads();
+  if (d_freq)
+    for (int r = threadIdx.x; r < R; r += blockDim.x) atomicAdd(d_freq + r, red[r]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -551,6 +612,27 @@ int eqf_rbf_expnorm_bwd(const float* len, const float* d_out, int E, int R, cons
   if (E <= 0) return 0;
   hipLaunchKernelGGL(rbf_expnorm_dlen_kernel, dim3(eqf_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, len, d_out, E, R,
                      means, betas, alpha, cutoff, d_len);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_rbf_bessel_fwd(const float* len, int E, int R, const float* freq, float cutoff, float* out, void* stream) {
+  if (!len || !freq || !out || cutoff <= 0.f) return EQF_E_BADARG;
+  if (E <= 0) return 0;
+  const long total = (long)E * R;
+  hipLaunchKernelGGL(rbf_bessel_fwd_kernel, dim3(eqf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, len, total, R,
+                     freq, 1.f / cutoff, sqrtf(2.f / (cutoff * cutoff * cutoff)), out);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_rbf_bessel_bwd(const float* len, const float* d_out, int E, int R, const float* freq, float cutoff,
+                       float* d_freq, float* d_len, void* stream) {
+  if (!len || !d_out || !freq || cutoff <= 0.f) return EQF_E_BADARG;
+  if (E <= 0) return 0;
+  const int EPB = 64;
+  hipLaunchKernelGGL(rbf_bessel_bwd_kernel, dim3(eqf_cdiv(E, EPB)), dim3(256), sizeof(float) * R, (hipStream_t)stream, len,
+                     d_out, E, R, freq, 1.f / cutoff, sqrtf(2.f / (cutoff * cutoff * cutoff)), d_len, d_freq, EPB);
   EQF_CHECK_LAUNCH();
   return 0;
 }

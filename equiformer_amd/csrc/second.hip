@@ -511,6 +511,48 @@ __global__ __launch_bounds__(256) void rbf_gauss_bwd2_param_kernel(const float* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------- spherical Bessel basis
+// h_k(x) = nc env(x) sin(f_k x) / x, x = len / rc (graph.hip rbf_bessel_*; GemNet RadialBasis of ocpmodels).
+// first backward: d_len[e] = (1/rc) sum_k g[e,k] h_k'(x).  One wave per edge; g_freq accumulated through LDS.
+__global__ __launch_bounds__(256) void rbf_bessel_bwd2_kernel(const float* __restrict__ len, const float* __restrict__ g,
+                                                              const float* __restrict__ cd, int E, int R,
+                                                              const float* __restrict__ freq, float inv_rc, float nc,
+                                                              float* __restrict__ g_len, float* __restrict__ g_g,
+                                                              float* __restrict__ g_freq, int EPB) {
+  extern __shared__ float red2[];  // [R]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) red2[r] = 0.f;
+  __syncthreads();
+  const int e0 = blockIdx.x * EPB, e1 = min(E, e0 + EPB);
+  for (int e = e0 + wave; e < e1; e += 4) {
+    const float x = len[e] * inv_rc, cdv = cd[e] * inv_rc;
+    float en0 = 0.f, en1 = 0.f, en2 = 0.f;
+    if (x < 1.f) {
+      const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x;
+      en0 = 1.f + x5 * (-21.f + x * (35.f - 15.f * x));
+      en1 = x4 * (-105.f + x * (210.f - 105.f * x));
+      en2 = x3 * (-420.f + x * (1050.f - 630.f * x));
+    }
+    const float ix = 1.f / x;
+    float acc = 0.f;
+    for (int r = lane; r < R; r += 64) {
+      const float f = freq[r], sn = sinf(f * x), cs = cosf(f * x);
+      const float s0 = sn * ix, s1 = f * cs * ix - sn * ix * ix;
+      const float s2 = -f * f * sn * ix - 2.f * f * cs * ix * ix + 2.f * sn * ix * ix * ix;
+      const float h1 = nc * (en1 * s0 + en0 * s1);
+      const float h2 = nc * (en2 * s0 + 2.f * en1 * s1 + en0 * s2);
+      const float gv = g[(long)e * R + r];
+      g_g[(long)e * R + r] = cdv * h1;
+      acc += gv * h2;
+      atomicAdd(&red2[r], cdv * gv * nc * (en1 * cs - en0 * f * sn));  // d h_k' / d f_k
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) g_len[e] = cdv * acc * inv_rc;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += blockDim.x) atomicAdd(g_freq + r, red2[r]);
+}
+
 // ---------------------------------------------------------------------------------------------- edge geometry
 // first backward: d_vec = grad_vec ( <d_sh, sh(vec)> + d_len |vec| ) =: grad psi.  With c = cotangent of d_vec:
 //   g_vec = Hessian(psi) c,  g_dsh = J_sh c,  g_dlen = <c, vec> / |vec|  -- all three are the eps parts of the first-order
@@ -652,6 +694,18 @@ int eqf_edge_geom_bwd2(const float* vec, const float* d_sh, const float* d_len, 
   if (E <= 0) return 0;
   hipLaunchKernelGGL(edge_geom_bwd2_kernel, dim3(eqf_cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, vec, d_sh, d_len,
                      c_vec, E, lmax, g_vec, g_dsh, g_dlen);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_rbf_bessel_bwd2(const float* len, const float* d_out, const float* c_len, int E, int R, const float* freq,
+                        float cutoff, float* g_len, float* g_dout, float* g_freq, void* stream) {
+  if (!len || !d_out || !c_len || !freq || !g_len || !g_dout || !g_freq || cutoff <= 0.f) return EQF_E_BADARG;
+  if (E <= 0) return 0;
+  const int EPB = 64;
+  hipLaunchKernelGGL(rbf_bessel_bwd2_kernel, dim3(eqf_cdiv(E, EPB)), dim3(256), sizeof(float) * R, (hipStream_t)stream, len,
+                     d_out, c_len, E, R, freq, 1.f / cutoff, sqrtf(2.f / (cutoff * cutoff * cutoff)), g_len, g_dout, g_freq,
+                     EPB);
   EQF_CHECK_LAUNCH();
   return 0;
 }

@@ -63,6 +63,8 @@ SIGNATURES = {
     "eqf_rbf_gaussian_bwd": [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "eqf_rbf_expnorm_fwd": [c_fp, c_int, c_int, c_fp, c_fp, _f, _f, c_fp, c_fp],
     "eqf_rbf_expnorm_bwd": [c_fp, c_fp, c_int, c_int, c_fp, c_fp, _f, _f, c_fp, c_fp],
+    "eqf_rbf_bessel_fwd": [c_fp, c_int, c_int, c_fp, _f, c_fp, c_fp],
+    "eqf_rbf_bessel_bwd": [c_fp, c_fp, c_int, c_int, c_fp, _f, c_fp, c_fp, c_fp],
     "eqf_gemm_nn": [c_fp, EqfRows, c_fp, c_int, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
     "eqf_gemm_nt": [c_fp, EqfRows, c_fp, c_int, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
     "eqf_gemm_tn": [c_fp, EqfRows, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
@@ -105,6 +107,7 @@ SIGNATURES = {
     "eqf_rbf_expnorm_bwd2": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, _f, _f, c_fp, c_fp, c_fp],
     "eqf_rbf_gaussian_bwd2": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, _f, c_fp, c_fp, c_fp, c_fp, c_fp,
                               c_fp, c_fp],
+    "eqf_rbf_bessel_bwd2": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, _f, c_fp, c_fp, c_fp, c_fp],
     "eqf_edge_geom_bwd2": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
     "eqf_prof_enable": [ctypes.c_char_p],
     "eqf_prof_report": [ctypes.c_char_p, c_int],

@@ -12,7 +12,7 @@ from ..graph import EdgeGraph
 from ..irreps import Irreps
 from .layers import (Activation, EdgeContext, EdgeDegreeEmbeddingNetwork, EquivariantLayerNormV2,  # noqa: F401
                      FeedForwardNetwork, FullyConnectedTensorProductRescale, GaussianRadialBasisLayer, GraphAttention,
-                     LinearRS, NodeEmbeddingNetwork, ScaledScatter, SeparableFCTP, TransBlock, get_norm_layer)
+                     LinearRS, NodeEmbeddingNetwork, RadialBasis, ScaledScatter, SeparableFCTP, TransBlock, get_norm_layer)
 from .registry import register_model
 
 _RESCALE = True
@@ -81,7 +81,7 @@ class _Trunk(nn.Module):
         if self.basis_type == "gaussian":
             self.rbf = GaussianRadialBasisLayer(self.number_of_basis, cutoff=self.max_radius)
         elif self.basis_type == "bessel":
-            raise NotImplementedError("the 'bessel' basis needs ocpmodels' RadialBasis (un-vendored); out of scope")
+            self.rbf = RadialBasis(self.number_of_basis, cutoff=self.max_radius, rbf={"name": "spherical_bessel"})
         else:
             raise ValueError
 
@@ -98,7 +98,7 @@ class _Trunk(nn.Module):
         no_wd_list = []
         named = {name for name, _ in self.named_parameters()}
         for module_name, module in self.named_modules():
-            if isinstance(module, (nn.Linear, nn.LayerNorm, EquivariantLayerNormV2, GaussianRadialBasisLayer)):
+            if isinstance(module, (nn.Linear, nn.LayerNorm, EquivariantLayerNormV2, GaussianRadialBasisLayer, RadialBasis)):
                 for parameter_name, _ in module.named_parameters():
                     if isinstance(module, nn.Linear) and "weight" in parameter_name:
                         continue

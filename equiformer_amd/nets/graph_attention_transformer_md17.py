@@ -16,7 +16,7 @@ from .. import ops
 from ..graph import EdgeGraph
 from ..irreps import Irreps
 from .graph_attention_transformer import _Trunk
-from .layers import ExpNormalSmearing, GaussianRadialBasisLayer
+from .layers import ExpNormalSmearing, GaussianRadialBasisLayer, RadialBasis
 from .registry import register_model
 
 _MAX_ATOM_TYPE = 64
@@ -53,7 +53,7 @@ class GraphAttentionTransformerMD17(_Trunk):
             self.rbf = ExpNormalSmearing(cutoff_lower=0.0, cutoff_upper=self.max_radius, num_rbf=self.number_of_basis,
                                          trainable=False)
         elif self.basis_type == "bessel":
-            raise NotImplementedError("the 'bessel' basis needs ocpmodels' RadialBasis (un-vendored); out of scope")
+            self.rbf = RadialBasis(self.number_of_basis, cutoff=self.max_radius, rbf={"name": "spherical_bessel"})
         else:
             raise ValueError
 
@@ -82,6 +82,30 @@ def _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, **over):
               drop_path_rate=0.0, mean=task_mean, std=task_std, scale=None, atomref=atomref)
     kw.update(over)
     return GraphAttentionTransformerMD17(**kw)
+
+
+@register_model
+def graph_attention_transformer_l2_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None, task_std=None,
+                                        **kwargs):
+    """[ref: nets/graph_attention_transformer_md17.py:330-347] linear messages, Gaussian basis, alpha_drop 0.2"""
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, basis_type="gaussian", alpha_drop=0.2,
+                 nonlinear_message=False)
+
+
+@register_model
+def graph_attention_transformer_nonlinear_bessel_l2_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                         task_std=None, **kwargs):
+    """[ref: nets/graph_attention_transformer_md17.py:387-404]"""
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, basis_type="bessel")
+
+
+@register_model
+def graph_attention_transformer_nonlinear_bessel_l3_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                         task_std=None, **kwargs):
+    """[ref: nets/graph_attention_transformer_md17.py:484-501]"""
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, basis_type="bessel",
+                 irreps_node_embedding="128x0e+64x1e+64x2e+32x3e", irreps_sh="1x0e+1x1e+1x2e+1x3e",
+                 irreps_head="32x0e+16x1e+16x2e+8x3e", irreps_mlp_mid="384x0e+192x1e+192x2e+96x3e")
 
 
 @register_model

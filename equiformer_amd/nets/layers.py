@@ -254,6 +254,31 @@ class ExpNormalSmearing(nn.Module):
         return ops.rbf_expnorm(dist, self.means, self.betas, self.alpha, self.cutoff_upper)
 
 
+class SphericalBesselBasis(nn.Module):
+    """Holds `frequencies` under the reference's key `rbf.rbf.frequencies` (ocpmodels gemnet/layers/radial_basis.py)."""
+
+    def __init__(self, num_radial, cutoff):
+        super().__init__()
+        self.frequencies = nn.Parameter(torch.tensor([math.pi * k for k in range(1, num_radial + 1)], dtype=torch.float32))
+
+
+class RadialBasis(nn.Module):
+    """ocpmodels' RadialBasis(num_radial, cutoff, rbf={'name': 'spherical_bessel'}) with the default polynomial
+    envelope (exponent 5) [ref call sites: nets/graph_attention_transformer.py:786-788, ..._md17.py:178-180]; the
+    arithmetic is `eqf_rbf_bessel_*` (csrc/graph.hip)."""
+
+    def __init__(self, num_radial, cutoff, rbf=None, envelope=None):
+        super().__init__()
+        name = (rbf or {"name": "spherical_bessel"}).get("name")
+        if name != "spherical_bessel" or (envelope or {"exponent": 5}).get("exponent", 5) != 5:
+            raise NotImplementedError("only the spherical-Bessel basis with the exponent-5 envelope is on the hot path")
+        self.cutoff = float(cutoff)
+        self.rbf = SphericalBesselBasis(num_radial, cutoff)
+
+    def forward(self, dist, *unused):
+        return ops.rbf_bessel(dist, self.rbf.frequencies, self.cutoff)
+
+
 # ------------------------------------------------------------------------------------------------- edge context
 class EdgeContext:
     """Per-forward geometry shared by every block: the dst-sorted graph, spherical harmonics, radial basis and

@@ -1042,6 +1042,66 @@ def rbf_expnorm(length, means, betas, alpha, cutoff):
     return _RbfExpNorm.apply(length, means, betas, float(alpha), float(cutoff))
 
 
+class _RbfBesselBwd(Function):
+    @staticmethod
+    def forward(ctx, length, freq, dout, cutoff):
+        dout = _c(dout)
+        _chk(dout)
+        dlen = torch.empty_like(length)
+        dfreq = _zeros_like(freq)
+        call("eqf_rbf_bessel_bwd", _p(length), _p(dout), length.shape[0], freq.numel(), _p(freq), cutoff, _p(dfreq),
+             _p(dlen), _stream())
+        ctx.save_for_backward(length, freq, dout)
+        ctx.cutoff = cutoff
+        if not _want_param_grads():
+            return dlen, None
+        ctx.mark_non_differentiable(dfreq)
+        return dlen, dfreq
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c_len, _cf=None):
+        length, freq, dout = ctx.saved_tensors
+        c_len = _c(c_len)
+        _chk(c_len)
+        g_len, g_dout = torch.empty_like(length), torch.empty_like(dout)
+        g_freq = _zeros_like(freq)
+        call("eqf_rbf_bessel_bwd2", _p(length), _p(dout), _p(c_len), length.shape[0], freq.numel(), _p(freq), ctx.cutoff,
+             _p(g_len), _p(g_dout), _p(g_freq), _stream())
+        return g_len, g_freq, g_dout, None
+
+
+class _RbfBessel(Function):
+    @staticmethod
+    def forward(ctx, length, freq, cutoff):
+        _chk(length, freq)
+        E, R = length.shape[0], freq.numel()
+        out = torch.empty((E, R), device=length.device, dtype=torch.float32)
+        call("eqf_rbf_bessel_fwd", _p(length), E, R, _p(freq), cutoff, _p(out), _stream())
+        ctx.save_for_backward(length, freq)
+        ctx.cutoff = cutoff
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        length, freq = ctx.saved_tensors
+        if torch.is_grad_enabled() and ctx.needs_input_grad[0]:  # create_graph
+            dlen, dfreq = _RbfBesselBwd.apply(length, freq, dout, ctx.cutoff)
+            return dlen, _guard_opt(dfreq, dout, "Bessel frequency gradient"), None
+        dout = _c(dout)
+        _chk(dout)
+        dlen = torch.empty_like(length) if ctx.needs_input_grad[0] else None
+        dfreq = _zeros_like(freq) if (ctx.needs_input_grad[1] and _want_param_grads()) else None
+        call("eqf_rbf_bessel_bwd", _p(length), _p(dout), length.shape[0], freq.numel(), _p(freq), ctx.cutoff, _p(dfreq),
+             _p(dlen), _stream())
+        return dlen, dfreq, None
+
+
+def rbf_bessel(length, freq, cutoff):
+    """Spherical Bessel basis with polynomial envelope (ocpmodels RadialBasis, 'spherical_bessel')."""
+    return _RbfBessel.apply(length, _c(freq), float(cutoff))
+
+
 # ------------------------------------------------------------------------------------------------- DTP
 def _coupling_fwd(sh, table):
     E = sh.shape[0]

@@ -135,6 +135,15 @@ int eqf_rbf_expnorm_fwd(const float* len, int E, int R, const float* means, cons
 int eqf_rbf_expnorm_bwd(const float* len, const float* d_out, int E, int R, const float* means,
                         const float* betas, float alpha, float cutoff, float* d_len, void* stream);
 
+/* Spherical Bessel basis with the polynomial envelope (exponent 5): x = len / rc,
+ * out[e,k] = env(x) sqrt(2 / rc^3) sin(freq_k x) / x, env = 1 - 21 x^5 + 35 x^6 - 15 x^7 for x < 1, else 0; freq trainable.
+ * [ref: RadialBasis(rbf={'name': 'spherical_bessel'}) of ocpmodels 0.0.3 (gemnet/layers/radial_basis.py; un-vendored
+ * dependency, restated), constructed at nets/graph_attention_transformer.py:786-788 and ..._md17.py:178-180]
+ * bwd: d_freq[R] ACCUMULATED (may be NULL), d_len[E] written (may be NULL). */
+int eqf_rbf_bessel_fwd(const float* len, int E, int R, const float* freq, float cutoff, float* out, void* stream);
+int eqf_rbf_bessel_bwd(const float* len, const float* d_out, int E, int R, const float* freq, float cutoff,
+                       float* d_freq, float* d_len, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense contractions on the matrix cores (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32)
  * ------------------------------------------------------------------------------------------- */
@@ -371,6 +380,9 @@ int eqf_rbf_expnorm_bwd2(const float* len, const float* d_out, const float* c_le
 int eqf_rbf_gaussian_bwd2(const float* len, const float* d_out, const float* c_len, int E, int R, const float* mean,
                           const float* std, const float* weight, const float* bias, float cutoff, float* g_len,
                           float* g_dout, float* g_mean, float* g_std, float* g_weight, float* g_bias, void* stream);
+/* as above for the spherical Bessel basis; g_freq[R] ACCUMULATED */
+int eqf_rbf_bessel_bwd2(const float* len, const float* d_out, const float* c_len, int E, int R, const float* freq,
+                        float cutoff, float* g_len, float* g_dout, float* g_freq, void* stream);
 /* c_vec [E,3]: cotangent of d_vec.  g_vec[E,3] written; g_dsh[E,(lmax+1)^2] and g_dlen[E] written if non-NULL;
  * d_sh / d_len may be NULL exactly as in eqf_edge_geom_bwd. */
 int eqf_edge_geom_bwd2(const float* vec, const float* d_sh, const float* d_len, const float* c_vec, int E, int lmax,

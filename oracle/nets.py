@@ -273,6 +273,40 @@ class ExpNormalSmearing(nn.Module):
         return cut * torch.exp(-self.betas * (torch.exp(self.alpha * (-d + self.cutoff_lower)) - self.means) ** 2)
 
 
+class SphericalBesselBasis(nn.Module):
+    """[dep] ocpmodels 0.0.3 (commit d2aaaeb, docs/env_setup.md:18-26 of the reference), models/gemnet/layers/
+    radial_basis.py -- un-vendored; restated from GemNet's published definition: sqrt(2 / c^3) sin(f_k x) / x with
+    x = d / c and trainable frequencies f_k initialised to k pi."""
+
+    def __init__(self, num_radial, cutoff):
+        super().__init__()
+        self.norm_const = math.sqrt(2.0 / (cutoff ** 3))
+        self.frequencies = nn.Parameter(torch.tensor([math.pi * k for k in range(1, num_radial + 1)], dtype=torch.float32))
+
+    def forward(self, d_scaled):
+        return self.norm_const / d_scaled[:, None] * torch.sin(self.frequencies * d_scaled[:, None])
+
+
+class RadialBasis(nn.Module):
+    """[dep] ocpmodels RadialBasis(num_radial, cutoff, rbf={'name': 'spherical_bessel'}) with its default polynomial
+    envelope of exponent 5: env(x) = 1 + a x^p + b x^(p+1) + c x^(p+2) for x < 1 (a = -(p+1)(p+2)/2, b = p(p+2),
+    c = -p(p+1)/2), 0 beyond.  [ref call sites: nets/graph_attention_transformer.py:786-788, ..._md17.py:178-180]"""
+
+    def __init__(self, num_radial, cutoff, rbf=None, envelope=None):
+        super().__init__()
+        assert (rbf or {"name": "spherical_bessel"})["name"] == "spherical_bessel"
+        self.inv_cutoff = 1.0 / cutoff
+        p = 5
+        self.p, self.a, self.b, self.c = p, -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
+        self.rbf = SphericalBesselBasis(num_radial, cutoff)
+
+    def forward(self, d, *unused):
+        x = d * self.inv_cutoff
+        env = 1 + self.a * x ** self.p + self.b * x ** (self.p + 1) + self.c * x ** (self.p + 2)
+        env = torch.where(x < 1, env, torch.zeros_like(x))
+        return env[:, None] * self.rbf(x)
+
+
 # ---------------------------------------------------------------------------- graph_attention_transformer.py
 def DepthwiseTensorProduct(irreps_in, irreps_edge, irreps_node_output, internal_weights=False, bias=True):
     irreps_in, irreps_edge, irreps_node_output = Irreps(irreps_in), Irreps(irreps_edge), Irreps(irreps_node_output)
@@ -498,6 +532,8 @@ class _Base(nn.Module):
             self.rbf = GaussianRadialBasisLayer(number_of_basis, cutoff=max_radius)
         elif basis_type == "exp":
             self.rbf = ExpNormalSmearing(0.0, max_radius, number_of_basis)
+        elif basis_type == "bessel":
+            self.rbf = RadialBasis(number_of_basis, cutoff=max_radius, rbf={"name": "spherical_bessel"})
         else:
             raise ValueError
         self.edge_deg_embed = EdgeDegreeEmbeddingNetwork(self.irreps_node_embedding, self.irreps_edge_attr,

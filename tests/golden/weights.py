@@ -10,7 +10,9 @@ def fill_deterministic(model, seed):
         for name, p in model.named_parameters():
             n = rng.standard_normal(tuple(p.shape))
             leaf = name.split(".")[-1]
-            if name.startswith("rbf."):
+            if leaf == "frequencies":        # Bessel basis: keep the k pi ladder, perturbed by 1 %
+                v = p.detach().double().numpy() * (1.0 + 0.01 * n)
+            elif name.startswith("rbf."):
                 v = {"mean": np.abs(n) * 0.5, "std": 0.3 + 0.2 * np.abs(n), "weight": 1.0 + 0.05 * n, "bias": 0.05 * n}[leaf]
             elif leaf == "affine_weight" or (leaf == "weight" and p.dim() == 1 and "tp." not in name):
                 v = 1.0 + 0.1 * n            # equivariant / radial LayerNorm gains

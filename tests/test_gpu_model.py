@@ -231,3 +231,68 @@ def test_md17_l3_full_size_training_step_runs():
             assert torch.isfinite(p.grad).all(), name
             n += 1
     assert n > 100
+
+
+@pytest.mark.parametrize("basis,nonlinear", [("bessel", True), ("gaussian", False)])
+def test_md17_variants_energy_forces_and_force_loss_gradients(basis, nonlinear):
+    """The other MD17 families of the reference (Bessel radial basis: ..._nonlinear_bessel_l2_md17 :387-404; linear
+    messages + Gaussian basis: ..._l2_md17 :330-347) on reduced models: energies, forces and the second-order gradients
+    of a force loss against the fp64 oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+    from weights import fill_deterministic
+    from equiformer_amd.nets.graph_attention_transformer_md17 import GraphAttentionTransformerMD17
+    from equiformer_amd.synthetic import md17_aspirin_batch
+    dev = _dev()
+    kw = dict(irreps_in="64x0e", max_radius=5.0, number_of_basis=32, basis_type=basis,
+              **dict(mg.SMALL_L2, nonlinear_message=nonlinear))
+    ref = fill_deterministic(onets.GraphAttentionTransformerMD17(**kw), 31).double().train()
+    mod = GraphAttentionTransformerMD17(**kw)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mod = mod.to(dev).train()
+    d = md17_aspirin_batch(2, seed=6)
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(2, 1, generator=g, dtype=torch.float64)
+    B = torch.randn(42, 3, generator=g, dtype=torch.float64)
+    Er, Fr = ref(d["z"], d["pos"].double(), d["batch"])
+    gr = torch.autograd.grad((a * Er).sum() + (B * Fr).sum(), list(ref.parameters()), allow_unused=True)
+    E, F = mod(d["z"].to(dev), d["pos"].to(dev), d["batch"].to(dev))
+    gg = torch.autograd.grad((a.float().to(dev) * E).sum() + (B.float().to(dev) * F).sum(), list(mod.parameters()),
+                             allow_unused=True)
+    assert _rel(E, Er) < 1e-4 and _rel(F, Fr) < 1e-4
+    worst = ("", 0.0)
+    for (n, _), x, r in zip(ref.named_parameters(), gg, gr):
+        if r is None or r.abs().max() == 0:
+            continue
+        assert x is not None, n
+        e = _rel(x, r)
+        if e > worst[1]:
+            worst = (n, e)
+    print("%s / nonlinear=%s: worst second-order gradient error %s %.3e" % ((basis, nonlinear) + worst))
+    assert worst[1] < 1e-4, worst
+
+
+def test_qm9_bessel_model_parity():
+    """graph_attention_transformer_nonlinear_bessel_l2 [ref: nets/graph_attention_transformer.py:959-975] at full size."""
+    from equiformer_amd import nets
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = _dev()
+    torch.manual_seed(0)
+    kw = dict(irreps_in="5x0e", irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6, irreps_sh="1x0e+1x1e+1x2e",
+              max_radius=5.0, number_of_basis=128, fc_neurons=[64, 64], basis_type="bessel", irreps_feature="512x0e",
+              irreps_head="32x0e+16x1e+8x2e", num_heads=4, nonlinear_message=True, irreps_mlp_mid="384x0e+192x1e+96x2e",
+              alpha_drop=0.2)
+    ref = onets.GraphAttentionTransformer(**kw).double().eval()
+    mod = nets.model_entrypoint("graph_attention_transformer_nonlinear_bessel_l2")(irreps_in="5x0e", radius=5.0)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mod = mod.to(dev).eval()
+    d = qm9_like_batch(4, 18, side=6.5, seed=3)
+    yr = ref(None, d["pos"].double(), d["batch"], d["z"])
+    y = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
+    assert _rel(y, yr) < 1e-4
+    gr = torch.autograd.grad(yr.sum(), [ref.rbf.rbf.frequencies, ref.blocks[0].ga.sep_act.dtp_rad.net[0].weight])
+    gg = torch.autograd.grad(y.sum(), [mod.rbf.rbf.frequencies, mod.blocks[0].ga.sep_act.dtp_rad.net[0].weight])
+    for x, r in zip(gg, gr):
+        assert _rel(x, r) < 1e-4

@@ -217,6 +217,35 @@ def test_rbf_gaussian_bwd2():
     _compare(lambda le, mu, sd, w, b: ops.rbf_gaussian(le, mu, sd, w, b, 5.0), ref, [length, mean, std, weight, bias], [0], 20)
 
 
+def test_rbf_bessel_fwd_bwd_bwd2():
+    """Spherical Bessel basis (ocpmodels RadialBasis, restated in oracle/nets.py) : values, first and second derivatives
+    wrt the edge length, the trainable frequencies and the output cotangent."""
+    from equiformer_amd import ops
+    from oracle import nets as onets
+    ref = onets.RadialBasis(16, cutoff=5.0, rbf={"name": "spherical_bessel"}).double()
+    g = torch.Generator().manual_seed(23)
+    length = (torch.rand(211, generator=g, dtype=torch.float64) * 5.4 + 0.5).requires_grad_(True)  # some beyond the cutoff
+    freq = (ref.rbf.frequencies.detach().double() * (1.0 + 0.01 * torch.randn(16, generator=g, dtype=torch.float64))).requires_grad_(True)
+
+    def fref(le, fr):
+        x = le / 5.0
+        env = 1 + ref.a * x ** 5 + ref.b * x ** 6 + ref.c * x ** 7
+        env = torch.where(x < 1, env, torch.zeros_like(x))
+        return env[:, None] * (ref.rbf.norm_const / x[:, None] * torch.sin(fr * x[:, None]))
+
+    with torch.no_grad():  # the closed form above IS the module
+        assert (fref(length, ref.rbf.frequencies.double()) - ref(length)).abs().max() < 1e-12
+    _compare(lambda le, fr: ops.rbf_bessel(le, fr, 5.0), fref, [length, freq], [0], 24)
+    # first-order gradient wrt the frequencies (a parameter: no second derivative through it, that raises by design)
+    dev = _dev()
+    le, fr = length.detach().float().to(dev).requires_grad_(True), freq.detach().float().to(dev).requires_grad_(True)
+    go = torch.randn(211, 16, generator=g, dtype=torch.float64)
+    g_hip = torch.autograd.grad(ops.rbf_bessel(le, fr, 5.0), [le, fr], go.float().to(dev))
+    g_ref = torch.autograd.grad(fref(length, freq), [length, freq], go)
+    for x, r in zip(g_hip, g_ref):
+        assert _rel(x, r) < TOL
+
+
 @pytest.mark.parametrize("lmax", [1, 2, 3])
 def test_edge_geometry_bwd2(lmax):
     from types import SimpleNamespace

@@ -50,9 +50,14 @@ def test_registry_and_factories():
     # variants outside the hot path fail loudly instead of silently degrading
     m = nets.model_entrypoint("graph_attention_transformer_l2")("5x0e", 5.0)  # linear-message variant is built
     assert sum(p.numel() for p in m.parameters()) == 3008515 and hasattr(m.blocks[0].ga, "sep")
-    with pytest.raises(NotImplementedError):
-        nets.model_entrypoint("graph_attention_transformer_nonlinear_bessel_l2")("5x0e", 5.0)
-    with pytest.raises(NotImplementedError):
+    mb = nets.model_entrypoint("graph_attention_transformer_nonlinear_bessel_l2")("5x0e", 5.0)  # Bessel basis: built
+    assert "rbf.rbf.frequencies" in dict(mb.named_parameters()) and "rbf.rbf.frequencies" in mb.no_weight_decay()
+    # 128 frequencies replace the Gaussian layer's mean / std / weight / bias (2 * 128 + 2)
+    assert sum(p.numel() for p in mb.parameters()) == 3531715 - (2 * 128 + 2) + 128
+    for name in ("graph_attention_transformer_l2_md17", "graph_attention_transformer_nonlinear_bessel_l2_md17",
+                 "graph_attention_transformer_nonlinear_bessel_l3_md17", "graph_attention_transformer_nonlinear_l2_md17"):
+        assert callable(nets.model_entrypoint(name))
+    with pytest.raises(NotImplementedError):  # E(3) (parity-aware) irreps are not on the hot path
         nets.model_entrypoint("graph_attention_transformer_nonlinear_l2_e3")("5x0e", 5.0)
 
 
