@@ -39,7 +39,11 @@ SegTab make_segtab(const eqf_irreps& ir) {
 }
 
 // ---------------------------------------------------------------------------------------------- layer norm
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// x2 / xsum optional: the residual add in front of the norm (x + x2 is normalised and also written to xsum, which the
+// next residual connection consumes) -- one pass instead of an element-wise add launch plus a re-read.  Every lane
+// re-forms the sums it needs (no read-back of values another lane stored).
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                            float* __restrict__ xsum, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y,
                                                             float* __restrict__ rstd, float* __restrict__ mean0,
                                                             int rows, SegTab T, float eps) {
@@ -47,20 +51,22 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (long)row * T.D;
+  const float* x2r = x2 ? x2 + (long)row * T.D : nullptr;
+  float* sr = x2 ? xsum + (long)row * T.D : nullptr;
   float* yr = y + (long)row * T.D;
   bool first0 = true;
   for (int s = 0; s < T.nseg; ++s) {
-    const float* xs = xr + T.off[s];
+    const int off = T.off[s];
     const int n = T.len[s], mul = T.mul[s];
     float mean = 0.f;
     if (T.l[s] == 0) {
       float sum = 0.f;
-      for (int i = lane; i < n; i += 64) sum += xs[i];
+      for (int i = lane; i < n; i += 64) sum += xr[off + i] + (x2r ? x2r[off + i] : 0.f);
       mean = wave_sum(sum) / n;
     }
     float sq = 0.f;
     for (int i = lane; i < n; i += 64) {
-      const float v = xs[i] - mean;
+      const float v = xr[off + i] + (x2r ? x2r[off + i] : 0.f) - mean;
       sq += v * v;
     }
     const float rs = rsqrtf(wave_sum(sq) / n + eps);
@@ -72,22 +78,26 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float* ws = w + T.woff[s];
     for (int i = lane; i < n; i += 64) {
       const int u = i % mul;
-      float v = (xs[i] - mean) * rs * ws[u];
+      const float xv = xr[off + i] + (x2r ? x2r[off + i] : 0.f);
+      if (sr) sr[off + i] = xv;
+      float v = (xv - mean) * rs * ws[u];
       if (T.boff[s] >= 0) v += b[T.boff[s] + u];
-      yr[T.off[s] + i] = v;
+      yr[off + i] = v;
     }
   }
 }
 
-// dx only; affine-parameter gradients are column reductions done by layernorm_wgrad_kernel
+// Backward: dx = LN'(dy) (+ dres, the gradient arriving at the normalised sum from the residual branch); one wave per row.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ dy, const float* __restrict__ rstd,
-                                                            float* __restrict__ dx, int rows, SegTab T) {
+                                                            const float* __restrict__ dy, const float* __restrict__ dres,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            int rows, SegTab T) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (long)row * T.D;
   const float* gr = dy + (long)row * T.D;
+  const float* rr = dres ? dres + (long)row * T.D : nullptr;
   float* dr = dx + (long)row * T.D;
   for (int s = 0; s < T.nseg; ++s) {
     const float* xs = xr + T.off[s];
@@ -113,11 +123,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = lane; i < n; i += 64) {
       const float g = gs[i] * ws[i % mul];
       const float xh = (xs[i] - mean) * rs;
-      dr[T.off[s] + i] = rs * (g - sg - xh * sgx);
+      float v = rs * (g - sg - xh * sgx);
+      if (rr) v += rr[T.off[s] + i];
+      dr[T.off[s] + i] = v;
     }
   }
 }
 
+// (Two restructurings of this reduction were measured in round 2 and dropped: folding it into the dx kernel with one
+// atomic per (workgroup, column) -- 61 us at 2 304 rows, because same-address fp32 atomics retire at ~0.35 ns each
+// (175 k of them) -- and a wave-per-row-block version with few fat workgroups -- 127 us, 64 waves cannot hide the load
+// latency.  The column-per-thread kernel below stays at 25 us.)
 // d_weight[woff+u] += sum_rows sum_m dy*xhat ; d_bias[boff+u] += sum_rows dy.   One thread per row column,
 // each block reduces CH rows, atomics at the end (columns of the same channel collide only (2l+1) ways).
 __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -507,26 +523,33 @@ extern "C" {
 
 const char* eqf_version(void) { return "equiformer_hip 0.1 gfx950"; }
 
-int eqf_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd, float* mean0,
-                      int rows, const eqf_irreps* irreps, float eps, void* stream) {
+int eqf_add_layernorm_fwd(const float* x, const float* x2, float* xsum, const float* weight, const float* bias, float* y,
+                          float* rstd, float* mean0, int rows, const eqf_irreps* irreps, float eps, void* stream) {
   if (!x || !weight || !bias || !y || !rstd || !mean0 || !irreps || irreps->nseg < 1 || irreps->nseg > EQF_MAX_SEG)
     return EQF_E_BADARG;
+  if ((x2 != nullptr) != (xsum != nullptr)) return EQF_E_BADARG;
   if (rows <= 0) return 0;
   const SegTab T = make_segtab(*irreps);
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, x,
-                     weight, bias, y, rstd, mean0, rows, T, eps);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, x, x2,
+                     xsum, weight, bias, y, rstd, mean0, rows, T, eps);
   EQF_CHECK_LAUNCH();
   return 0;
 }
 
-int eqf_layernorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd, const float* mean0,
-                      float* dx, float* d_weight, float* d_bias, int rows, const eqf_irreps* irreps, void* stream) {
+int eqf_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* rstd, float* mean0,
+                      int rows, const eqf_irreps* irreps, float eps, void* stream) {
+  return eqf_add_layernorm_fwd(x, nullptr, nullptr, weight, bias, y, rstd, mean0, rows, irreps, eps, stream);
+}
+
+int eqf_add_layernorm_bwd(const float* x, const float* weight, const float* dy, const float* dres, const float* rstd,
+                          const float* mean0, float* dx, float* d_weight, float* d_bias, int rows,
+                          const eqf_irreps* irreps, void* stream) {
   if (!x || !weight || !dy || !rstd || !mean0 || !dx || !irreps || irreps->nseg < 1 || irreps->nseg > EQF_MAX_SEG)
     return EQF_E_BADARG;
   if (rows <= 0) return 0;
   const SegTab T = make_segtab(*irreps);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, x,
-                     weight, dy, rstd, dx, rows, T);
+                     weight, dy, dres, rstd, dx, rows, T);
   EQF_CHECK_LAUNCH();
   if (d_weight && d_bias) {
     const int CH = 16;  // few rows per thread: the row loop is a chain of dependent loads
@@ -535,6 +558,11 @@ int eqf_layernorm_bwd(const float* x, const float* weight, const float* dy, cons
     EQF_CHECK_LAUNCH();
   }
   return 0;
+}
+
+int eqf_layernorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd, const float* mean0,
+                      float* dx, float* d_weight, float* d_bias, int rows, const eqf_irreps* irreps, void* stream) {
+  return eqf_add_layernorm_bwd(x, weight, dy, nullptr, rstd, mean0, dx, d_weight, d_bias, rows, irreps, stream);
 }
 
 int eqf_gate_fwd(const float* in, float* out, int rows, int S, const eqf_irreps* gated, float c_silu, float c_sig,

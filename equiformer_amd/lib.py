@@ -80,6 +80,8 @@ SIGNATURES = {
     "eqf_sfc_bwd_weight": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, c_fp, c_int, _PP, c_fp, c_int, c_fp],
     "eqf_layernorm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, _f, c_fp],
     "eqf_layernorm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, c_fp],
+    "eqf_add_layernorm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, _f, c_fp],
+    "eqf_add_layernorm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, c_fp],
     "eqf_gate_fwd": [c_fp, c_fp, c_int, c_int, _P_IRR, _f, _f, c_fp],
     "eqf_gate_bwd": [c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _f, c_fp],
     "eqf_silu_fwd": [c_fp, c_fp, _long, _f, c_fp],

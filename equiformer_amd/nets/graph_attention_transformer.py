@@ -118,10 +118,11 @@ class _Trunk(nn.Module):
         _, edge_length, edge_sh = ops.edge_geometry(pos, offsets, graph, self.lmax_sh)
         edge_scalars = self.rbf(edge_length)
         ectx = EdgeContext(graph, edge_sh, edge_scalars)
-        node_features = node_embedding + self.edge_deg_embed(node_embedding, ectx)
+        # residual stream kept as a lazy pair (a, b) = a + b: each add is folded into the layer norm that consumes it
+        a, b = node_embedding, self.edge_deg_embed(node_embedding, ectx)
         for blk in self.blocks:
-            node_features = blk(node_input=node_features, node_attr=None, ectx=ectx)
-        node_features = self.norm(node_features)
+            a, b = blk.forward_pair(a, b, node_attr=None, ectx=ectx)
+        _, node_features = self.norm.forward_sum(a, b)
         outputs = self.head(node_features)
         return self.scale_scatter(outputs, graph.mol_ptr, graph.batch, graph.num_graphs)
 

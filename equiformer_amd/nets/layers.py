@@ -173,6 +173,13 @@ class EquivariantLayerNormV2(nn.Module):
                 node_input.shape[-1], self.layout.dim))
         return ops.layer_norm(node_input, self.affine_weight, self.affine_bias, self.layout, self.eps)
 
+    def forward_sum(self, a, b):
+        """(a + b, norm(a + b)) in one launch: the residual add that precedes every norm of the transformer."""
+        if a.shape[-1] != self.layout.dim:
+            raise AssertionError("`ix` should have reached node_input.size(-1) ({}), but it ended at {}".format(
+                a.shape[-1], self.layout.dim))
+        return ops.add_layer_norm(a, b, self.affine_weight, self.affine_bias, self.layout, self.eps)
+
     def __repr__(self):
         return "{}({}, eps={})".format(self.__class__.__name__, self.irreps, self.eps)
 
@@ -569,6 +576,17 @@ class TransBlock(nn.Module):
         if self.ffn_shortcut is not None:
             node_output = self.ffn_shortcut(node_output, node_attr)
         return node_output + node_features
+
+    def forward_pair(self, a, b, node_attr=None, ectx=None):
+        """The same block on a lazily summed input node_input = a + b, returning its output as a lazy pair as well
+        (node_output, node_features): every residual add then rides on the layer norm that follows it (norm_1 here,
+        norm_2, and the next block's norm_1 or the model's final norm) instead of being its own launch."""
+        node_input, h = self.norm_1.forward_sum(a, b)
+        node_output, h2 = self.norm_2.forward_sum(node_input, self.ga(h, ectx=ectx))
+        node_features = self.ffn(h2, node_attr)
+        if self.ffn_shortcut is not None:
+            node_output = self.ffn_shortcut(node_output, node_attr)
+        return node_output, node_features
 
 
 class NodeEmbeddingNetwork(nn.Module):

@@ -212,6 +212,52 @@ def layer_norm(x, weight, bias, layout, eps=1e-5):
     return _LayerNorm.apply(x, weight, bias, layout, eps)
 
 
+class _AddLayerNorm(Function):
+    """(s, y) = (a + b, LayerNorm(a + b)): the residual add in front of a norm and the norm in one launch; the backward
+    folds the gradient arriving at s from the residual branch into the norm's input gradient (no element-wise add
+    launches in either direction) and accumulates the affine-parameter gradients in the same kernel."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, layout, eps):
+        a, b = _c(a), _c(b)
+        _chk(a, b, weight, bias)
+        n = a.shape[0]
+        s = torch.empty_like(a)
+        y = torch.empty_like(a)
+        rstd = torch.empty((n, len(layout.segs)), device=a.device, dtype=torch.float32)
+        mean0 = torch.empty((n,), device=a.device, dtype=torch.float32)
+        call("eqf_add_layernorm_fwd", _p(a), _p(b), _p(s), _p(weight), _p(bias), _p(y), _p(rstd), _p(mean0), n,
+             layout.c_ref, float(eps), _stream())
+        ctx.save_for_backward(s, weight, rstd, mean0)
+        ctx.layout, ctx.nb, ctx.eps = layout, bias.numel(), eps
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, weight, rstd, mean0 = ctx.saved_tensors
+        if dy is None:  # the normalised branch is unused: identity on the sum
+            return ds, ds, None, None, None, None
+        if torch.is_grad_enabled():  # create_graph: differentiable norm backward + a differentiable add
+            dx, dw, db = _LayerNormBwd.apply(s, weight, dy, rstd, mean0, ctx.layout, ctx.eps, ctx.nb)
+            d = dx if ds is None else dx + ds
+            return d, d, _guard_opt(dw, dy, "layer-norm weight gradient"), _guard_opt(db, dy, "layer-norm bias gradient"), \
+                None, None
+        dy = _c(dy)
+        ds = _c(ds) if ds is not None else None
+        _chk(dy, ds)
+        d = torch.empty_like(s)
+        want = _want_param_grads()
+        dw, db = _zeros2(weight.numel(), ctx.nb, s.device) if want else (None, None)
+        call("eqf_add_layernorm_bwd", _p(s), _p(weight), _p(dy), _p(ds), _p(rstd), _p(mean0), _p(d), _p(dw), _p(db), s.shape[0],
+             ctx.layout.c_ref, _stream())
+        return d, d, dw, db, None, None
+
+
+def add_layer_norm(a, b, weight, bias, layout, eps=1e-5):
+    """(a + b, LayerNorm(a + b))."""
+    return _AddLayerNorm.apply(a, b, weight, bias, layout, eps)
+
+
 # ------------------------------------------------------------------------------------------------- per-degree linear
 class LinearSpec:
     """Pairs (degree-wise GEMMs) of a LinearRS / FCTP-with-scalar-attr between two row layouts.

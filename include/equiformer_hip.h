@@ -263,6 +263,18 @@ int eqf_layernorm_bwd(const float* x, const float* weight, const float* dy, cons
                       const float* mean0, float* dx, float* d_weight, float* d_bias, int rows,
                       const eqf_irreps* irreps, void* stream);
 
+/* The same with the residual add in front of the norm folded in [ref: TransBlock.forward, nets/graph_attention_transformer.py:
+ * 639-667: node_output = node_input + ga(...); ffn(norm_2(node_output)) ...]: xsum = x + x2 is written and normalised in one
+ * pass (x2 == xsum == NULL: plain layer norm).  bwd: dx = LN'(dy) + dres (dres = gradient arriving at xsum from the
+ * residual branch, may be NULL); d_weight / d_bias ACCUMULATED (both may be NULL together); `x` is the normalised input
+ * (xsum of the forward). */
+int eqf_add_layernorm_fwd(const float* x, const float* x2, float* xsum, const float* weight, const float* bias,
+                          float* y, float* rstd, float* mean0, int rows, const eqf_irreps* irreps, float eps,
+                          void* stream);
+int eqf_add_layernorm_bwd(const float* x, const float* weight, const float* dy, const float* dres, const float* rstd,
+                          const float* mean0, float* dx, float* d_weight, float* d_bias, int rows,
+                          const eqf_irreps* irreps, void* stream);
+
 /* Gate: in = [scalars(S) | gates(G) | gated segments], out = [c_silu*silu(scalars) | gated * c_sig*sigmoid(gates)].
  * `gated` lists the l>0 segments (sum of mul = G).  in rows have S+G+dim(gated) floats, out rows S+dim(gated).
  * [ref: nets/fast_activation.py:132-148] */
