@@ -250,7 +250,7 @@ struct RowsP {  // one problem of a grouped launch (A operand from memory)
   int vecA, vecB;
   int exp;
 };
-constexpr int MAX_GROUP = 4;
+constexpr int MAX_GROUP = 8;
 struct RowsGroup {
   int n;
   RowsP p[MAX_GROUP];
@@ -800,7 +800,7 @@ int eqf_gemm_group(const eqf_gemm_desc* d, int n, void* stream) {
     int maxm = 0, maxn = 0, z = 0;
     double flops = 0, bytes = 0;
     for (int i = 0; i < n; ++i) {
-      if (d[i].kind != 2) continue;
+      if (d[i].kind != 2 && d[i].kind != 3) continue;
       if (!d[i].A || !d[i].B || !d[i].C || d[i].ra.d < 1 || d[i].rc.d < 1) return EQF_E_BADARG;
       if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0) continue;
       // kind 2:  C[M,N] (plain, leading dimension ldb) += sum over K rows of A[row, 0:M]^T B'[row, 0:N], B' given as (C-field rows rc)
@@ -811,8 +811,9 @@ int eqf_gemm_group(const eqf_gemm_desc* d, int n, void* stream) {
       P.rows_per_step = BK;
       P.vecA = rows_vec_ok(d[i].A, d[i].ra);
       P.vecB = rows_vec_ok(d[i].B, d[i].rc);
-      P.csA = nullptr;
-      P.csB = const_cast<float*>(d[i].bias);  // kind 2: `bias` = accumulator of the column sums of B' (may be null)
+      // kind 2: `bias` = accumulator of the column sums of B'; kind 3: of A (the operand that is dy; may be null)
+      P.csA = d[i].kind == 3 ? const_cast<float*>(d[i].bias) : nullptr;
+      P.csB = d[i].kind == 2 ? const_cast<float*>(d[i].bias) : nullptr;
       const int tiles = eqf_cdiv(P.M, 64) * eqf_cdiv(P.N, 64);
       const int total_steps = eqf_cdiv(P.R, BK);
       int ksplit = 1024 / (tiles > 0 ? tiles : 1);

@@ -340,25 +340,46 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------- LN(C<=64) + SiLU
 __global__ __launch_bounds__(256) void lnsilu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, int rows,
-                                                         int C, float eps) {
+                                                         int C, float eps, int G) {
+  // group g = blockIdx.y of a [rows][G][C] tensor with per-group affine parameters (G == 1: plain rows)
+  const long ld = (long)G * C;
+  {
+    const int g_ = blockIdx.y * C;
+    x += g_;
+    gamma += g_;
+    beta += g_;
+    y += g_;
+  }
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
   const bool act = lane < C;
-  const float v = act ? x[(long)row * C + lane] : 0.f;
+  const float v = act ? x[(long)row * ld + lane] : 0.f;
   const float mean = wave_sum(v) / C;
   const float d = act ? v - mean : 0.f;
   const float rs = rsqrtf(wave_sum(d * d) / C + eps);
   if (act) {
     const float z = d * rs * gamma[lane] + beta[lane];
-    y[(long)row * C + lane] = z * sigmoidf_(z);
+    y[(long)row * ld + lane] = z * sigmoidf_(z);
   }
 }
 
 __global__ __launch_bounds__(256) void lnsilu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ dy,
                                                          float* __restrict__ dx, float* __restrict__ d_gamma,
-                                                         float* __restrict__ d_beta, int rows, int C, float eps) {
+                                                         float* __restrict__ d_beta, int rows, int C, float eps, int G) {
+  // group g = blockIdx.y of a [rows][G][C] tensor with per-group affine parameters (G == 1: plain rows)
+  const long ld = (long)G * C;
+  {
+    const int g_ = blockIdx.y * C;
+    x += g_;
+    gamma += g_;
+    beta += g_;
+    dy += g_;
+    dx += g_;
+    d_gamma += g_;
+    d_beta += g_;
+  }
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * WAVES_PER_BLOCK;
@@ -366,19 +387,19 @@ __global__ __launch_bounds__(256) void lnsilu_bwd_kernel(const float* __restrict
   const float gm = act ? gamma[lane] : 0.f, bt = act ? beta[lane] : 0.f;
   float acc_g = 0.f, acc_b = 0.f;
   for (int row = wave_global; row < rows; row += nwaves) {
-    const float v = act ? x[(long)row * C + lane] : 0.f;
+    const float v = act ? x[(long)row * ld + lane] : 0.f;
     const float mean = wave_sum(v) / C;
     const float d = act ? v - mean : 0.f;
     const float rs = rsqrtf(wave_sum(d * d) / C + eps);
     const float xh = d * rs;
     const float z = xh * gm + bt;
-    const float dz = act ? dy[(long)row * C + lane] * dsilu(z) : 0.f;
+    const float dz = act ? dy[(long)row * ld + lane] * dsilu(z) : 0.f;
     acc_g += dz * xh;
     acc_b += dz;
     const float g = dz * gm;
     const float sg = wave_sum(g) / C;
     const float sgx = wave_sum(g * xh) / C;
-    if (act) dx[(long)row * C + lane] = rs * (g - sg - xh * sgx);
+    if (act) dx[(long)row * ld + lane] = rs * (g - sg - xh * sgx);
   }
   __shared__ float red_g[WAVES_PER_BLOCK][64], red_b[WAVES_PER_BLOCK][64];
   red_g[threadIdx.x >> 6][lane] = acc_g;
@@ -404,7 +425,19 @@ template <int U>
 __global__ __launch_bounds__(256) void lnsilu_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ dy,
                                                           float* __restrict__ dx, float* __restrict__ d_gamma,
-                                                          float* __restrict__ d_beta, int rows, int C, float eps) {
+                                                          float* __restrict__ d_beta, int rows, int C, float eps, int G) {
+  // group g = blockIdx.y of a [rows][G][C] tensor with per-group affine parameters (G == 1: plain rows)
+  const long ld = (long)G * C;
+  {
+    const int g_ = blockIdx.y * C;
+    x += g_;
+    gamma += g_;
+    beta += g_;
+    dy += g_;
+    dx += g_;
+    d_gamma += g_;
+    d_beta += g_;
+  }
   const int lane = threadIdx.x & 63, sub = lane & 15, rw = lane >> 4;
   const int wave_global = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * WAVES_PER_BLOCK;
@@ -422,8 +455,8 @@ __global__ __launch_bounds__(256) void lnsilu_bwd4_kernel(const float* __restric
     for (int u = 0; u < U; ++u) {
       const int row = base + u * 4 + rw;
       ok[u] = act && row < rows;
-      v[u] = ok[u] ? *reinterpret_cast<const float4*>(x + (long)row * C + c0) : zero4;
-      g[u] = ok[u] ? *reinterpret_cast<const float4*>(dy + (long)row * C + c0) : zero4;
+      v[u] = ok[u] ? *reinterpret_cast<const float4*>(x + (long)row * ld + c0) : zero4;
+      g[u] = ok[u] ? *reinterpret_cast<const float4*>(dy + (long)row * ld + c0) : zero4;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -445,7 +478,7 @@ __global__ __launch_bounds__(256) void lnsilu_bwd4_kernel(const float* __restric
         float4 o;
         o.x = rs * (gg.x - sg - xh.x * sgx), o.y = rs * (gg.y - sg - xh.y * sgx);
         o.z = rs * (gg.z - sg - xh.z * sgx), o.w = rs * (gg.w - sg - xh.w * sgx);
-        *reinterpret_cast<float4*>(dx + (long)(base + u * 4 + rw) * C + c0) = o;
+        *reinterpret_cast<float4*>(dx + (long)(base + u * 4 + rw) * ld + c0) = o;
       }
     }
   }
@@ -609,35 +642,46 @@ int eqf_silu_bwd(const float* x, const float* dy, float* dx, long n, float c, vo
   return 0;
 }
 
-int eqf_lnsilu_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps,
-                   void* stream) {
-  if (!x || !gamma || !beta || !y || C < 1) return EQF_E_BADARG;
+int eqf_lnsilu_group_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, int groups,
+                         float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || C < 1 || groups < 1 || groups > 65535) return EQF_E_BADARG;
   if (C > 64) return EQF_E_UNSUPPORTED;
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(lnsilu_fwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, x,
-                     gamma, beta, y, rows, C, eps);
+  hipLaunchKernelGGL(lnsilu_fwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK), groups), dim3(256), 0, (hipStream_t)stream,
+                     x, gamma, beta, y, rows, C, eps, groups);
   EQF_CHECK_LAUNCH();
   return 0;
 }
 
+int eqf_lnsilu_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps,
+                   void* stream) {
+  return eqf_lnsilu_group_fwd(x, gamma, beta, y, rows, C, 1, eps, stream);
+}
+
 int eqf_lnsilu_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx, float* d_gamma,
                    float* d_beta, int rows, int C, float eps, void* stream) {
-  if (!x || !gamma || !beta || !dy || !dx || !d_gamma || !d_beta || C < 1) return EQF_E_BADARG;
+  return eqf_lnsilu_group_bwd(x, gamma, beta, dy, dx, d_gamma, d_beta, rows, C, 1, eps, stream);
+}
+
+int eqf_lnsilu_group_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
+                         float* d_gamma, float* d_beta, int rows, int C, int groups, float eps, void* stream) {
+  if (!x || !gamma || !beta || !dy || !dx || !d_gamma || !d_beta || C < 1 || groups < 1 || groups > 65535)
+    return EQF_E_BADARG;
   if (C > 64) return EQF_E_UNSUPPORTED;
   if (rows <= 0) return 0;
   if (C % 4 == 0) {
     constexpr int U = 2;  // 8 rows per wave step, 2 steps per wave
     int blocks = eqf_cdiv(rows, WAVES_PER_BLOCK * 4 * U * 2);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(lnsilu_bwd4_kernel<U>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy, dx,
-                       d_gamma, d_beta, rows, C, eps);
+    hipLaunchKernelGGL(lnsilu_bwd4_kernel<U>, dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy,
+                       dx, d_gamma, d_beta, rows, C, eps, groups);
     EQF_CHECK_LAUNCH();
     return 0;
   }
   int blocks = eqf_cdiv(rows, WAVES_PER_BLOCK * 2);  // two rows per wave: the loop is a chain of dependent reductions
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(lnsilu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy, dx,
-                     d_gamma, d_beta, rows, C, eps);
+  hipLaunchKernelGGL(lnsilu_bwd_kernel, dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy, dx,
+                     d_gamma, d_beta, rows, C, eps, groups);
   EQF_CHECK_LAUNCH();
   return 0;
 }

@@ -88,6 +88,8 @@ SIGNATURES = {
     "eqf_silu_bwd": [c_fp, c_fp, c_fp, _long, _f, c_fp],
     "eqf_lnsilu_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, _f, c_fp],
     "eqf_lnsilu_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _f, c_fp],
+    "eqf_lnsilu_group_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
+    "eqf_lnsilu_group_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
     "eqf_embed_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
     "eqf_embed_bwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
     "eqf_gather_add_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp],

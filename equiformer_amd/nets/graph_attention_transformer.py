@@ -12,7 +12,7 @@ from ..graph import EdgeGraph
 from ..irreps import Irreps
 from .layers import (Activation, EdgeContext, EdgeDegreeEmbeddingNetwork, EquivariantLayerNormV2,  # noqa: F401
                      FeedForwardNetwork, FullyConnectedTensorProductRescale, GaussianRadialBasisLayer, GraphAttention,
-                     LinearRS, NodeEmbeddingNetwork, RadialBasis, ScaledScatter, SeparableFCTP, TransBlock, get_norm_layer)
+                     LinearRS, NodeEmbeddingNetwork, RadialBank, RadialBasis, ScaledScatter, SeparableFCTP, TransBlock, get_norm_layer)
 from .registry import register_model
 
 _RESCALE = True
@@ -114,10 +114,26 @@ class _Trunk(nn.Module):
             if hasattr(m, "use_fused"):
                 m.use_fused = "legacy" if flag == "legacy" else bool(flag)
 
+    def _radial_bank(self):
+        bank = self.__dict__.get("_bank")
+        if bank is None:
+            mods = [self.edge_deg_embed.rad]
+            for blk in self.blocks:
+                ga = blk.ga
+                mods.append(ga.sep_act.dtp_rad if ga.nonlinear_message else ga.sep.dtp_rad)
+            bank = RadialBank(mods)
+            self.__dict__["_bank"] = bank  # plain attribute (not a sub-module, not copied into state_dict)
+        return bank if (bank.ok and self.use_radial_bank) else None
+
+    use_radial_bank = True
+
     def _trunk_forward(self, node_embedding, pos, graph, offsets=None):
         _, edge_length, edge_sh = ops.edge_geometry(pos, offsets, graph, self.lmax_sh)
         edge_scalars = self.rbf(edge_length)
-        ectx = EdgeContext(graph, edge_sh, edge_scalars)
+        # the radial MLPs of all blocks side by side (RadialBank); it has no second-order backward, so it steps aside when
+        # forces are being taken with create_graph (MD17 training)
+        bank = self._radial_bank() if not getattr(self, "_second_order_pass", False) else None
+        ectx = EdgeContext(graph, edge_sh, edge_scalars, radial_bank=bank)
         # residual stream kept as a lazy pair (a, b) = a + b: each add is folded into the layer norm that consumes it
         a, b = node_embedding, self.edge_deg_embed(node_embedding, ectx)
         for blk in self.blocks:

@@ -62,11 +62,12 @@ class GraphAttentionTransformerMD17(_Trunk):
         pos = pos.to(torch.float32).contiguous().requires_grad_(True)
         graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=1000)
         atom_embedding, _, _ = self.atom_embed(node_atom)
+        trainable = any(p.requires_grad for p in self.parameters())
+        second_order = self.training and trainable
+        self.__dict__["_second_order_pass"] = second_order  # read by _trunk_forward (radial bank: first-order only)
         energy = self._trunk_forward(atom_embedding, pos, graph)
         if self.scale is not None:
             energy = self.scale * energy
-        trainable = any(p.requires_grad for p in self.parameters())
-        second_order = self.training and trainable
         with ops.input_grads_only():  # only d E / d pos is wanted here: no parameter gradients in this pass
             forces = -1 * torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy),
                                               create_graph=second_order, retain_graph=trainable)[0]

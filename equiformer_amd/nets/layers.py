@@ -230,6 +230,36 @@ class RadialProfile(nn.Module):
         return x
 
 
+class RadialBank:
+    """All RadialProfile MLPs of a model (one per transformer block + the edge-degree embedding) evaluated side by side
+    on the shared radial basis: every one of them maps the SAME edge_length_embedding through Linear-LN-SiLU-Linear-LN-
+    SiLU-Linear (+offset) with its own parameters [ref: nets/graph_attention_transformer.py:200-208,445-447,717;
+    forward :880-886].  Per module that is 5 launches forward and 10 backward on tensors of only 64 columns; side by
+    side it is ONE 128 -> G*64 GEMM, two grouped LayerNorm+SiLU launches and two grouped-GEMM launches for all G
+    modules (eqf_gemm_group / eqf_lnsilu_group_*), forward and backward alike.  A plain helper object: the parameters
+    stay where the reference's state_dict has them."""
+
+    def __init__(self, modules):
+        self.modules = [m for m in modules if m is not None]
+        mods = [list(m.net) for m in self.modules]
+        self.ok = len(self.modules) >= 2 and all(
+            len(ms) == 7 and ms[0].weight.shape == mods[0][0].weight.shape and ms[3].weight.shape == mods[0][3].weight.shape
+            and ms[3].weight.shape[0] == ms[3].weight.shape[1] and ms[0].weight.shape[0] <= 64 for ms in mods)
+
+    def forward(self, edge_scalars):
+        """-> {id(module): [E, weight_numel]}"""
+        ms = self.modules
+        G = len(ms)
+        C = ms[0].net[0].weight.shape[0]
+        cat = torch.cat
+        h = ops.dense_linear(edge_scalars, cat([m.net[0].weight for m in ms]), cat([m.net[0].bias for m in ms]))
+        h = ops.ln_silu(h, cat([m.net[1].weight for m in ms]), cat([m.net[1].bias for m in ms]), ms[0].net[1].eps, groups=G)
+        h = ops.grouped_linear(h, C, [m.net[3].weight for m in ms], [m.net[3].bias for m in ms], wide=True)
+        h = ops.ln_silu(h, cat([m.net[4].weight for m in ms]), cat([m.net[4].bias for m in ms]), ms[0].net[4].eps, groups=G)
+        outs = ops.grouped_linear(h, C, [m.net[6].weight for m in ms], [m.offset for m in ms], wide=False)
+        return {id(m): o for m, o in zip(ms, outs)}
+
+
 class GaussianRadialBasisLayer(nn.Module):
     def __init__(self, num_basis, cutoff):
         super().__init__()
@@ -291,9 +321,21 @@ class EdgeContext:
     """Per-forward geometry shared by every block: the dst-sorted graph, spherical harmonics, radial basis and
     the DTP coupling matrices (one tensor per distinct path table, computed once per forward)."""
 
-    def __init__(self, graph, edge_sh, edge_scalars):
+    def __init__(self, graph, edge_sh, edge_scalars, radial_bank=None):
         self.graph, self.edge_sh, self.edge_scalars = graph, edge_sh, edge_scalars
         self._coupling = {}
+        self._bank, self._radial = radial_bank, None
+
+    def radial(self, module):
+        """Per-edge path weights of `module` (a RadialProfile): from the model's radial bank when there is one (all
+        modules evaluated together on first use), otherwise the module on its own."""
+        if self._bank is not None:
+            if self._radial is None:
+                self._radial = self._bank.forward(self.edge_scalars)
+            w = self._radial.get(id(module))
+            if w is not None:
+                return w
+        return module(self.edge_scalars)
 
     def coupling(self, table):
         c = self._coupling.get(table.key)
@@ -384,7 +426,7 @@ class SeparableFCTP(nn.Module):
         table = self.dtp.table
         M = ectx.coupling(table)
         internal = self.dtp.tp.internal_weights
-        w = self.dtp_rad(ectx.edge_scalars) if self.dtp_rad is not None else None
+        w = ectx.radial(self.dtp_rad) if self.dtp_rad is not None else None
         bias = self.lin._bias()
         if use_fused is True and self.sfc_spec.supported:
             out = ops.sep_fctp(node_input, M, w, self.flat_weight(), bias, self.sfc_spec)
@@ -492,7 +534,7 @@ class GraphAttention(nn.Module):
         sa = self.sep_act
         table = sa.dtp.table
         M = ectx.coupling(table)
-        weight = sa.dtp_rad(ectx.edge_scalars)
+        weight = ectx.radial(sa.dtp_rad)
         if self.use_fused is True and self.act_sfc_spec.supported:
             value, alpha = ops.sep_fctp(message, M, weight, sa.flat_weight(), sa.lin._bias(), self.act_sfc_spec,
                                         weight2=self.sep_alpha.tp.weight, bias2=self.sep_alpha._bias())
@@ -512,7 +554,7 @@ class GraphAttention(nn.Module):
         sep = self.sep
         table = sep.dtp.table
         M = ectx.coupling(table)
-        weight = sep.dtp_rad(ectx.edge_scalars)
+        weight = ectx.radial(sep.dtp_rad)
         W = sep.lin.tp.weight
         (l, _, K0, _, N0, off0) = sep.lin.spec.pairs[0]
         assert l == 0 and off0 == 0
@@ -639,7 +681,7 @@ class EdgeDegreeEmbeddingNetwork(nn.Module):
         # exp(ones): the same row for every node == lookup of row 0
         zeros = torch.zeros(g.N, dtype=torch.int32, device=node_input.device)
         node_features = ops.embed(zeros, self.exp.tp.weight.view(1, self.C), self.exp._bias(), self.D)
-        weight = self.rad(ectx.edge_scalars)
+        weight = ectx.radial(self.rad)
         src_features = ops.gather_add(node_features, None, g)
         M = ectx.coupling(self.dw.table)
         if self.use_fused is True and self.sfc_spec.supported:

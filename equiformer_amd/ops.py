@@ -285,9 +285,9 @@ class LinearSpec:
 
 
 def _gemm_group(descs, st):
-    """One launch per kind for up to 4 per-degree GEMMs (eqf_gemm_group)."""
-    for i in range(0, len(descs), 4):
-        chunk = descs[i:i + 4]
+    """One launch per kind for up to 8 GEMMs (eqf_gemm_group)."""
+    for i in range(0, len(descs), 8):
+        chunk = descs[i:i + 8]
         arr = (EqfGemmDesc * len(chunk))(*chunk)
         call("eqf_gemm_group", arr, len(chunk), st)
 
@@ -662,28 +662,34 @@ def scaled_silu(x, c):
 
 class _LnSilu(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, groups=1):
         x = _c(x)
         _chk(x, gamma, beta)
         y = torch.empty_like(x)
-        call("eqf_lnsilu_fwd", _p(x), _p(gamma), _p(beta), _p(y), x.shape[0], x.shape[1], eps, _stream())
+        call("eqf_lnsilu_group_fwd", _p(x), _p(gamma), _p(beta), _p(y), x.shape[0], x.shape[1] // groups, groups, eps,
+             _stream())
         ctx.save_for_backward(x, gamma, beta)
-        ctx.eps = eps
+        ctx.eps, ctx.groups = eps, groups
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta = ctx.saved_tensors
+        G = ctx.groups
         if torch.is_grad_enabled():  # create_graph
+            if G != 1:
+                raise NotImplementedError("grouped LayerNorm+SiLU has no second-order backward (the radial bank is "
+                                          "bypassed when forces are taken with create_graph)")
             dx, dg, db = _LnSiluBwd.apply(x, gamma, beta, dy, ctx.eps)
-            return dx, _guard_opt(dg, dy, "LayerNorm weight gradient"), _guard_opt(db, dy, "LayerNorm bias gradient"), None
+            return dx, _guard_opt(dg, dy, "LayerNorm weight gradient"), _guard_opt(db, dy, "LayerNorm bias gradient"), \
+                None, None
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
         dg, db = _zeros2(gamma.numel(), beta.numel(), x.device)
-        call("eqf_lnsilu_bwd", _p(x), _p(gamma), _p(beta), _p(dy), _p(dx), _p(dg), _p(db), x.shape[0], x.shape[1],
-             ctx.eps, _stream())
-        return dx, dg, db, None
+        call("eqf_lnsilu_group_bwd", _p(x), _p(gamma), _p(beta), _p(dy), _p(dx), _p(dg), _p(db), x.shape[0],
+             x.shape[1] // G, G, ctx.eps, _stream())
+        return dx, dg, db, None, None
 
 
 class _LnSiluBwd(Function):
@@ -715,8 +721,80 @@ class _LnSiluBwd(Function):
         return g_x, g_g, g_b, g_dy, None
 
 
-def ln_silu(x, gamma, beta, eps=1e-5):
-    return _LnSilu.apply(x, gamma, beta, eps)
+def ln_silu(x, gamma, beta, eps=1e-5, groups=1):
+    """silu(LayerNorm(x) * gamma + beta) on rows of C = x.shape[1] / groups channels; with groups > 1 the row holds
+    `groups` independent feature vectors with their own gamma / beta ([groups * C])."""
+    return _LnSilu.apply(x, gamma, beta, eps, int(groups))
+
+
+class _GroupedLinear(Function):
+    """G independent nn.Linear layers on the column blocks of one wide input: y_g = x[:, g K:(g+1) K] W_g^T + b_g, all G
+    GEMMs in ONE launch (eqf_gemm_group), forward and both gradients.  `wide`: the outputs form one [rows, sum N_g]
+    tensor (returned as such), otherwise G separate [rows, N_g] tensors.  params = (W_0..W_{G-1}, b_0..b_{G-1}).
+    First-order only (used by the radial bank, which steps aside under create_graph)."""
+
+    @staticmethod
+    def forward(ctx, x, K, wide, *params):
+        G = len(params) // 2
+        Ws, bs = params[:G], params[G:]
+        x = _c(x)
+        _chk(x, *Ws, *bs)
+        rows_n, ldx = x.shape
+        Ns = [int(W.shape[0]) for W in Ws]
+        assert ldx == G * K and all(W.shape[1] == K and W.is_contiguous() for W in Ws)
+        if wide:
+            out = torch.empty((rows_n, sum(Ns)), device=x.device, dtype=torch.float32)
+            outs, ldo, offs = [out] * G, sum(Ns), [sum(Ns[:g]) for g in range(G)]
+        else:
+            outs = [torch.empty((rows_n, n), device=x.device, dtype=torch.float32) for n in Ns]
+            ldo, offs = None, [0] * G
+        descs = [_desc(1, (x, g * K), rows(1, ldx, 0), (Ws[g], 0), K, (outs[g], offs[g]),
+                       rows(1, ldo if wide else Ns[g], 0), bs[g], rows_n, Ns[g], K) for g in range(G)]
+        _gemm_group(descs, _stream())
+        ctx.save_for_backward(x, *Ws)
+        ctx.meta = (G, K, wide, Ns, [b is not None for b in bs])
+        return out if wide else tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        x, *Ws = ctx.saved_tensors
+        G, K, wide, Ns, has_b = ctx.meta
+        rows_n, ldx = x.shape
+        dev = x.device
+        if wide:
+            dy = _c(dys[0])
+            _chk(dy)
+            ldd, offs, dyt = sum(Ns), [sum(Ns[:g]) for g in range(G)], [dy] * G
+        else:
+            dyt = [(_c(d) if d is not None else _zeros((rows_n, Ns[g]), dev)) for g, d in enumerate(dys)]
+            _chk(*dyt)
+            ldd, offs = None, [0] * G
+        st = _stream()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _gemm_group([_desc(0, (dyt[g], offs[g]), rows(1, ldd if wide else Ns[g], 0), (Ws[g], 0), K, (dx, g * K),
+                               rows(1, ldx, 0), None, rows_n, K, Ns[g]) for g in range(G)], st)
+        if not _want_param_grads():
+            return (dx, None, None) + (None,) * (2 * G)
+        sizes = [n * K for n in Ns] + [n if hb else 0 for n, hb in zip(Ns, has_b)]
+        flat = _zeros(sum(sizes), dev)
+        o, dWs, dbs = 0, [], []
+        for g in range(G):
+            dWs.append(flat[o:o + Ns[g] * K].view(Ns[g], K))
+            o += Ns[g] * K
+        for g in range(G):
+            dbs.append(flat[o:o + Ns[g]] if has_b[g] else None)
+            o += Ns[g] if has_b[g] else 0
+        # kind 3: dW_g[N_g, K] += dy_g^T x_g, db_g += column sums of dy_g (same launch)
+        _gemm_group([_desc(3, (dyt[g], offs[g]), rows(1, ldd if wide else Ns[g], 0), (x, g * K), K, (dWs[g], 0),
+                           rows(1, ldx, 0), dbs[g], Ns[g], K, rows_n) for g in range(G)], st)
+        return (dx, None, None) + tuple(dWs) + tuple(dbs)
+
+
+def grouped_linear(x, K, weights, biases, wide):
+    return _GroupedLinear.apply(x, int(K), bool(wide), *weights, *biases)
 
 
 # ------------------------------------------------------------------------------------------------- embedding

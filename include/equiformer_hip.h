@@ -179,11 +179,13 @@ int eqf_gemm_tn_colsum(const float* A, eqf_rows ra, const float* B, eqf_rows rb,
                        int R, float* colsum_a, float* colsum_b, void* stream);
 
 /* Several independent GEMMs in ONE launch per kind (the per-degree GEMMs of one irreps linear; the node-level linears
- * have only N ~ 2 k rows and are launch / latency bound).  n <= 4 problems.
+ * have only N ~ 2 k rows and are launch / latency bound; the radial MLPs of all blocks side by side).  n <= 8 problems.
  *   kind 0:  C[i,n] (=|+=) sum_k A[i,k] B[k,n] (+ bias)     A: M two-level rows (ra) x K, B plain [K,N] (ldb), C rows (rc)
  *   kind 1:  C[i,n] (=|+=) sum_k A[i,k] B[n,k] (+ bias)     B plain [N,K] (ldb)
  *   kind 2:  C[m,n] += sum_{i<K} A[i,m] B[i,n]              A: K two-level rows (ra) x M, B: K two-level rows (rc) x N,
- *                                                            C plain [M,N] with leading dimension ldb (atomics)
+ *                                                            C plain [M,N] with leading dimension ldb (atomics);
+ *                                                            `bias` (optional) accumulates the column sums of B
+ *   kind 3:  as kind 2, `bias` accumulates the column sums of A (nn.Linear orientation: dW[out,in] = dy^T x, db = colsum dy)
  * [ref: LinearRS / FullyConnectedTensorProductRescale, nets/tensor_product_rescale.py:125-136,171-174] */
 typedef struct eqf_gemm_desc {
   const float* A;
@@ -294,6 +296,15 @@ int eqf_lnsilu_fwd(const float* x, const float* gamma, const float* beta, float*
 /* dx written; d_gamma[C], d_beta[C] ACCUMULATED. */
 int eqf_lnsilu_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
                    float* d_gamma, float* d_beta, int rows, int C, float eps, void* stream);
+
+/* The same on a [rows][groups][C] tensor with per-group parameters gamma / beta [groups][C] (d_gamma / d_beta alike):
+ * the radial MLPs of all blocks of a model evaluated side by side on the shared radial basis
+ * [ref: every TransBlock owns a RadialProfile over the same edge_length_embedding,
+ *  nets/graph_attention_transformer.py:200-208,445-447,717 and :880-886]. */
+int eqf_lnsilu_group_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, int groups,
+                         float eps, void* stream);
+int eqf_lnsilu_group_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
+                         float* d_gamma, float* d_beta, int rows, int C, int groups, float eps, void* stream);
 
 /* Atom-type embedding: y[n, 0:C] = W[type[n], 0:C] + b[0:C], remaining D-C floats of the row zeroed
  * (LinearRS applied to a one-hot vector).  [ref: nets/graph_attention_transformer.py:682-690] */
