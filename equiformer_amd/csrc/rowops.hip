@@ -550,6 +550,39 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   if (rl == 0 && c < N) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
+
+// ---------------------------------------------------------------------------------------------- weight folding
+// SeparableFCTP with shared (internal) depth-wise weights [ref: nets/graph_attention_transformer.py:449-451 sep_value]:
+// Linear(DTP_w(x)) == Linear'(DTP_1(x)) with W'[row, :] = w[w_of_row[row]] * W[row, :] -- the fold and its two gradients.
+// W is the flat per-degree [K(l), N(l)] weight; row_start[r] = first element of row r.
+__global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ w,
+                                                       const int* __restrict__ row_start, const int* __restrict__ w_of_row,
+                                                       float* __restrict__ out, int rows) {
+  const int r = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float s = w[w_of_row[r]];
+  for (int i = row_start[r] + lane; i < row_start[r + 1]; i += 64) out[i] = W[i] * s;
+}
+
+// dW[i] = g[i] * w_row ; dw[w_of_row[r]] = <g[row], W[row]>  (rows and shared weights are in one-to-one correspondence)
+__global__ __launch_bounds__(256) void fold_bwd_kernel(const float* __restrict__ W, const float* __restrict__ w,
+                                                       const int* __restrict__ row_start, const int* __restrict__ w_of_row,
+                                                       const float* __restrict__ g, float* __restrict__ dW,
+                                                       float* __restrict__ dw, int rows) {
+  const int r = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const int j = w_of_row[r];
+  const float s = w[j];
+  float acc = 0.f;
+  for (int i = row_start[r] + lane; i < row_start[r + 1]; i += 64) {
+    const float gv = g[i];
+    dW[i] = gv * s;
+    acc = fmaf(gv, W[i], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dw[j] = acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -712,6 +745,26 @@ int eqf_colsum(const float* X, eqf_rows rx, int R, int N, float* out, void* stre
   const int RCH = 128;
   hipLaunchKernelGGL(colsum_kernel, dim3(eqf_cdiv(N, 64), eqf_cdiv(R, RCH)), dim3(256), 0, (hipStream_t)stream, X, rx.d,
                      rx.ld, rx.inner, R, N, out, RCH);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_fold_weight_fwd(const float* W, const float* w, const int* row_start, const int* w_of_row, float* out, int rows,
+                        void* stream) {
+  if (!W || !w || !row_start || !w_of_row || !out) return EQF_E_BADARG;
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(fold_fwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, W, w,
+                     row_start, w_of_row, out, rows);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_fold_weight_bwd(const float* W, const float* w, const int* row_start, const int* w_of_row, const float* g,
+                        float* dW, float* dw, int rows, void* stream) {
+  if (!W || !w || !row_start || !w_of_row || !g || !dW || !dw) return EQF_E_BADARG;
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(fold_bwd_kernel, dim3(eqf_cdiv(rows, WAVES_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, W, w,
+                     row_start, w_of_row, g, dW, dw, rows);
   EQF_CHECK_LAUNCH();
   return 0;
 }

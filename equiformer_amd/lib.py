@@ -90,6 +90,8 @@ SIGNATURES = {
     "eqf_lnsilu_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _f, c_fp],
     "eqf_lnsilu_group_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
     "eqf_lnsilu_group_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
+    "eqf_fold_weight_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp],
+    "eqf_fold_weight_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp],
     "eqf_embed_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
     "eqf_embed_bwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
     "eqf_gather_add_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp],

@@ -401,6 +401,15 @@ class SeparableFCTP(nn.Module):
                     elem.extend([idx[r + k]] * N)
                 r += K
             self.register_buffer("_elem_to_w", torch.tensor(elem, dtype=torch.long), persistent=False)
+            # rows of the flat lin weight: first element of every row and the shared weight that scales it (eqf_fold_weight_*)
+            starts, o = [], 0
+            for (l, _, K, _, N, w_off) in self.lin.spec.pairs:
+                assert w_off == o
+                starts.extend(range(o, o + K * N, N))
+                o += K * N
+            starts.append(o)
+            self.register_buffer("_row_start", torch.tensor(starts, dtype=torch.int32), persistent=False)
+            self.register_buffer("_w_of_row", torch.tensor(idx, dtype=torch.int32), persistent=False)
 
     def folded_lin_weight(self):
         """lin weight with the shared depth-wise weights folded into its rows:
@@ -419,6 +428,8 @@ class SeparableFCTP(nn.Module):
         if self.dtp.tp.internal_weights:
             # index_select, not weight[idx]: the backward of advanced indexing is index_put_(accumulate=True), which
             # sorts the 64 512 indices on the device (45 rocPRIM launches per block); index_select's is one index_add_
+            if self.lin.tp.weight.is_cuda:
+                return ops.fold_weight(self.lin.tp.weight, self.dtp.tp.weight, self._row_start, self._w_of_row)
             return self.lin.tp.weight * self.dtp.tp.weight.index_select(0, self._elem_to_w)
         return self.lin.tp.weight
 

@@ -797,6 +797,41 @@ def grouped_linear(x, K, weights, biases, wide):
     return _GroupedLinear.apply(x, int(K), bool(wide), *weights, *biases)
 
 
+class _FoldWeight(Function):
+    """W'[row, :] = w[w_of_row[row]] * W[row, :] on a flat per-degree weight (shared depth-wise weights folded into the
+    linear after the tensor product); multilinear, so the create_graph backward is itself made of fold products."""
+
+    @staticmethod
+    def forward(ctx, W, w, row_start, w_of_row):
+        W, w = _c(W), _c(w)
+        _chk(W, w, row_start, w_of_row)
+        out = torch.empty_like(W)
+        call("eqf_fold_weight_fwd", _p(W), _p(w), _p(row_start), _p(w_of_row), _p(out), w_of_row.numel(), _stream())
+        ctx.save_for_backward(W, w, row_start, w_of_row)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        W, w, row_start, w_of_row = ctx.saved_tensors
+        if torch.is_grad_enabled():  # create_graph: dW = fold(g, w); dw via the tensor identity (rare path, ATen)
+            dW = _FoldWeight.apply(g, w, row_start, w_of_row)
+            row_of = torch.repeat_interleave(torch.arange(w_of_row.numel(), device=W.device),
+                                             (row_start[1:] - row_start[:-1]).long())
+            dw = torch.zeros_like(w).index_add(0, w_of_row.long()[row_of], g * W)
+            return dW, dw, None, None
+        g = _c(g)
+        _chk(g)
+        dW = torch.empty_like(W)
+        dw = torch.zeros_like(w) if w.numel() != w_of_row.numel() else torch.empty_like(w)
+        call("eqf_fold_weight_bwd", _p(W), _p(w), _p(row_start), _p(w_of_row), _p(g), _p(dW), _p(dw), w_of_row.numel(),
+             _stream())
+        return dW, dw, None, None
+
+
+def fold_weight(W, w, row_start, w_of_row):
+    return _FoldWeight.apply(W, w, row_start, w_of_row)
+
+
 # ------------------------------------------------------------------------------------------------- embedding
 class _Embed(Function):
     @staticmethod

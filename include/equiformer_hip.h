@@ -306,6 +306,15 @@ int eqf_lnsilu_group_fwd(const float* x, const float* gamma, const float* beta, 
 int eqf_lnsilu_group_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
                          float* d_gamma, float* d_beta, int rows, int C, int groups, float eps, void* stream);
 
+/* Shared (internal) depth-wise weights folded into the rows of the linear that follows the tensor product:
+ * out[i] = W[i] * w[w_of_row[row(i)]] over the flat weight W (row r = elements row_start[r] .. row_start[r+1]); bwd: dW[i] =
+ * g[i] * w[...] and dw[w_of_row[r]] = <g[row r], W[row r]> (written; rows <-> shared weights one to one).
+ * [ref: SeparableFCTP(internal_weights=True) = sep_value, nets/graph_attention_transformer.py:449-451] */
+int eqf_fold_weight_fwd(const float* W, const float* w, const int* row_start, const int* w_of_row, float* out, int rows,
+                        void* stream);
+int eqf_fold_weight_bwd(const float* W, const float* w, const int* row_start, const int* w_of_row, const float* g,
+                        float* dW, float* dw, int rows, void* stream);
+
 /* Atom-type embedding: y[n, 0:C] = W[type[n], 0:C] + b[0:C], remaining D-C floats of the row zeroed
  * (LinearRS applied to a one-hot vector).  [ref: nets/graph_attention_transformer.py:682-690] */
 int eqf_embed_fwd(const int* type, const float* W, const float* b, float* y, int rows, int C, int D,
