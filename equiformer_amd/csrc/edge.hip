@@ -443,6 +443,9 @@ __global__ void attn_bwd_half_kernel(const float* __restrict__ alpha, const floa
       if (vb) d_logit[(long)eb * H + h] = db;
     }
   }
+  // the stash above was written by lanes 0 / 32 of THIS wave and is re-read below by its other lanes: same wave, same CU,
+  // so both accesses go through this CU's write-through L1; the workgroup fence (s_waitcnt vmcnt(0)) retires the stores
+  // before the loads are issued.  No other wave touches these addresses.
   __threadfence_block();
   for (int e = beg + lane; e < end; e += 64) {
     const float da = d_logit[(long)e * H + h];

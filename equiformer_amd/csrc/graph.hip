@@ -529,7 +529,10 @@ int eqf_csr_by_source(const int* src, const int* row_ptr, const int* mol_ptr, in
   if (!row_ptr || !mol_ptr || !src_perm || !src_ptr || !src) return EQF_E_BADARG;
   if (max_mol_nodes > CSR_MAX_NODES) return EQF_E_UNSUPPORTED;
   if (n_mol <= 0) return 0;
-  static bool attr = false;
+  static bool attr_done[64] = {};  // per device (function attribute)
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr = attr_done[dev_id & 63];
   if (!attr) {
     hipFuncSetAttribute((const void*)csr_by_source_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                         CSR_MAX_NODES * (int)sizeof(int));

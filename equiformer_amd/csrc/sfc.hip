@@ -1215,7 +1215,12 @@ int eqf_sfc_fwd(const float* x, const float* coupling, const float* w, const eqf
 
   hipStream_t st = (hipStream_t)stream;
   const int pid = eqf_prof_begin("sfc_fwd", st, sfc_flops(A.c), sfc_bytes(A.c));
-  static bool attr_set = false;
+  // the dynamic-LDS limit is a per-device function attribute: one flag per device (a process drives one GPU, but
+  // nothing in the ABI forbids several)
+  static bool attr_done[64] = {};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_done[dev_id & 63];
   if (!attr_set) {
     hipFuncSetAttribute((const void*)sfc_fwd_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
     hipFuncSetAttribute((const void*)sfc_fwd_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
@@ -1387,14 +1392,20 @@ int eqf_sfc_bwd_data(const float* x, const float* coupling, const float* w, cons
   dim3 grid(nblk);
   const int pid = eqf_prof_begin("sfc_bwd_data", st, sfc_flops(A.c), sfc_bytes(A.c));
   if (md <= 5) {
-    static bool attr5 = false;
+    static bool attr5_done[64] = {};
+    int dev5 = 0;
+    (void)hipGetDevice(&dev5);
+    bool& attr5 = attr5_done[dev5 & 63];
     if (!attr5) {
       hipFuncSetAttribute((const void*)sfc_bwd_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
       attr5 = true;
     }
     hipLaunchKernelGGL(sfc_bwd_kernel<5>, grid, dim3(256), (g_sfc_exp & 32) ? (size_t)100 * 1024 : lds, st, A);
   } else {
-    static bool attr7 = false;
+    static bool attr7_done[64] = {};
+    int dev7 = 0;
+    (void)hipGetDevice(&dev7);
+    bool& attr7 = attr7_done[dev7 & 63];
     if (!attr7) {
       hipFuncSetAttribute((const void*)sfc_bwd_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, SFC_LDS_LIMIT);
       attr7 = true;

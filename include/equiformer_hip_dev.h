@@ -1,0 +1,33 @@
+/*
+ * equiformer_hip_dev.h -- development entry points of libequiformer_hip.so.
+ *
+ * NOT part of the drop-in boundary (that is equiformer_hip.h): these switches exist for A/B measurements and
+ * phase timing of the fused SeparableFCTP and GEMM kernels (tools/sfc_exp.py, tools/bench_sfc.py, tools/sfc_race.py,
+ * tools/gemm_exp.py).  They change process-global state, are not thread safe and have no reference counterpart.  Nothing
+ * under equiformer_amd/ calls them.
+ */
+#ifndef EQUIFORMER_HIP_DEV_H
+#define EQUIFORMER_HIP_DEV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* workgroup ordering of the three sfc kernels: -1 defaults ({fwd 0, bwd_data 1, bwd_weight 1}), 0 x-fastest,
+ * 1 XCD-aware, 2 y-fastest */
+int eqf_sfc_debug_order(int mode);
+/* bit mask that switches phases of the sfc kernels off (1 no MFMA loop, 2 no generation / register epilogue, 4 no
+ * re-staging, 8 no weight loads, 16 paired workgroups, 32 force one workgroup per CU, 64 the non-default forward matrix
+ * step: split-precision bf16 x 6 -- see the note at g_sfc_x6_default in csrc/sfc.hip) */
+int eqf_sfc_debug_exp(int mask);
+/* 1 if the split-precision forward step is the default (it is not) */
+int eqf_sfc_debug_x6_default(void);
+/* 8 x u64 device counters the sfc kernels add per-phase cycle counts to; NULL disables */
+int eqf_sfc_debug_buffer(void* device_u64x8);
+/* gemm kernels: 1 no stores, 2 no MFMA */
+int eqf_gemm_debug_exp(int mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQUIFORMER_HIP_DEV_H */

@@ -20,6 +20,16 @@ def test_library_exports_every_declared_symbol(hip_lib):
         assert hasattr(hip_lib, name), name
     assert declared - {"eqf_version"} == set(lib.SIGNATURES), "ctypes table out of sync with the header"
     assert lib.version().startswith("equiformer_hip")
+    # and the other way round: every eqf_* symbol the shared object exports is declared -- in the public header or, for the
+    # development switches, in equiformer_hip_dev.h (which the product never binds)
+    import subprocess
+    dev = set(re.findall(r"\b(eqf_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "equiformer_hip_dev.h")).read()))
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("eqf_")}
+    # helper symbols shared between the translation units of the library (not entry points)
+    internal = {n for n in exported if n.startswith("eqf_prof_begin") or n.startswith("eqf_prof_end")}
+    assert exported - internal <= declared | dev, sorted(exported - internal - declared - dev)
+    assert not (dev & set(lib.SIGNATURES)), "development switches must stay out of the product's binding table"
 
 
 def test_struct_layouts_match_header():
