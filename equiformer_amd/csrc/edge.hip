@@ -70,6 +70,20 @@ __global__ __launch_bounds__(256) void segment_bcast_kernel(const float* __restr
   out[idx] = scale * x[(long)seg_of[row] * D + c];
 }
 
+// out[q,c] = s[seg_of[q]] * x[q,c]: per-graph stochastic depth (GraphDropPath).  Linear in x, so the same kernel is its
+// own backward (on dy) and second-order term.
+__global__ __launch_bounds__(256) void segment_scale_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                            const int* __restrict__ seg_of, float* __restrict__ out,
+                                                            long total4, int D4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const long row = idx / D4;
+  const float f = s[seg_of[row]];
+  float4 v = reinterpret_cast<const float4*>(x)[idx];
+  v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+  reinterpret_cast<float4*>(out)[idx] = v;
+}
+
 // ---------------------------------------------------------------------------------------------- DTP coupling
 __global__ __launch_bounds__(256) void coupling_fwd_kernel(const float* __restrict__ sh, const float* __restrict__ cg,
                                                            const eqf_dtp_paths P, float* __restrict__ M, long total) {
@@ -540,6 +554,17 @@ int eqf_segment_sum(const float* x, const int* ptr, const int* perm, float* out,
   if (nseg <= 0 || D <= 0) return 0;
   hipLaunchKernelGGL(segment_sum_kernel, dim3(nseg), dim3(128), 0, (hipStream_t)stream, x, ptr, perm, out, D, scale,
                      accumulate);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_segment_scale(const float* x, const float* s, const int* seg_of, float* out, int rows, int D, void* stream) {
+  if (!x || !s || !seg_of || !out) return EQF_E_BADARG;
+  if (D % 4) return EQF_E_UNSUPPORTED;
+  if (rows <= 0 || D <= 0) return 0;
+  const long total4 = (long)rows * (D / 4);
+  hipLaunchKernelGGL(segment_scale_kernel, dim3(eqf_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, s, seg_of,
+                     out, total4, D / 4);
   EQF_CHECK_LAUNCH();
   return 0;
 }

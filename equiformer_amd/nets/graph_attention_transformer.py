@@ -70,10 +70,11 @@ class _Trunk(nn.Module):
                 norm_layer=norm_layer))
         self.norm = get_norm_layer(norm_layer)(self.irreps_feature)
         self.out_dropout = None
-        self.head = nn.Sequential(
-            LinearRS(self.irreps_feature, self.irreps_feature, rescale=_RESCALE),
-            Activation(self.irreps_feature, kind="silu"),
-            LinearRS(self.irreps_feature, Irreps("1x0e"), rescale=_RESCALE))
+        if all(ir.l == 0 for _, ir in self.irreps_feature):  # otherwise the subclass brings its own head (OC20)
+            self.head = nn.Sequential(
+                LinearRS(self.irreps_feature, self.irreps_feature, rescale=_RESCALE),
+                Activation(self.irreps_feature, kind="silu"),
+                LinearRS(self.irreps_feature, Irreps("1x0e"), rescale=_RESCALE))
         self.scale_scatter = ScaledScatter(avg_num_nodes)
         self.apply(self._init_weights)
 
@@ -118,8 +119,7 @@ class _Trunk(nn.Module):
         bank = self.__dict__.get("_bank")
         if bank is None:
             mods = [self.edge_deg_embed.rad]
-            for blk in self.blocks:
-                ga = blk.ga
+            for ga in [blk.ga for blk in self.blocks] + self._attention_heads():
                 mods.append(ga.sep_act.dtp_rad if ga.nonlinear_message else ga.sep.dtp_rad)
             bank = RadialBank(mods)
             self.__dict__["_bank"] = bank  # plain attribute (not a sub-module, not copied into state_dict)
@@ -127,7 +127,19 @@ class _Trunk(nn.Module):
 
     use_radial_bank = True
 
+    def _attention_heads(self):
+        """GraphAttention modules that read the final features (OC20 auxiliary / attention heads); none by default."""
+        return []
+
     def _trunk_forward(self, node_embedding, pos, graph, offsets=None):
+        node_features, ectx = self._trunk_features(node_embedding, pos, graph, offsets)
+        if isinstance(self.head, GraphAttention):  # attention head (MD17 use_attn_head)
+            outputs = self.head(node_features, ectx=ectx)
+        else:
+            outputs = self.head(node_features)
+        return self.scale_scatter(outputs, graph.mol_ptr, graph.batch, graph.num_graphs)
+
+    def _trunk_features(self, node_embedding, pos, graph, offsets=None):
         _, edge_length, edge_sh = ops.edge_geometry(pos, offsets, graph, self.lmax_sh)
         edge_scalars = self.rbf(edge_length)
         # the radial MLPs of all blocks side by side (RadialBank); it has no second-order backward, so it steps aside when
@@ -139,8 +151,7 @@ class _Trunk(nn.Module):
         for blk in self.blocks:
             a, b = blk.forward_pair(a, b, node_attr=None, ectx=ectx)
         _, node_features = self.norm.forward_sum(a, b)
-        outputs = self.head(node_features)
-        return self.scale_scatter(outputs, graph.mol_ptr, graph.batch, graph.num_graphs)
+        return node_features, ectx
 
 
 class GraphAttentionTransformer(_Trunk):

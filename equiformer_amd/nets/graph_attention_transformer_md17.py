@@ -16,7 +16,7 @@ from .. import ops
 from ..graph import EdgeGraph
 from ..irreps import Irreps
 from .graph_attention_transformer import _Trunk
-from .layers import ExpNormalSmearing, GaussianRadialBasisLayer, RadialBasis
+from .layers import ExpNormalSmearing, GaussianRadialBasisLayer, GraphAttention, RadialBasis
 from .registry import register_model
 
 _MAX_ATOM_TYPE = 64
@@ -34,8 +34,6 @@ class GraphAttentionTransformerMD17(_Trunk):
                  norm_layer="layer", alpha_drop=0.2, proj_drop=0.0, out_drop=0.0, drop_path_rate=0.0, mean=None,
                  std=None, scale=None, atomref=None):
         super().__init__()
-        if use_attn_head:
-            raise NotImplementedError("use_attn_head=True is not used by any registered MD17 model")
         self.use_attn_head = use_attn_head
         self.task_mean, self.task_std, self.scale = mean, std, scale
         self.register_buffer("atomref", atomref)
@@ -45,6 +43,14 @@ class GraphAttentionTransformerMD17(_Trunk):
                           number_of_basis, fc_neurons, irreps_feature, irreps_head, num_heads, irreps_pre_attn,
                           rescale_degree, nonlinear_message, irreps_mlp_mid, norm_layer, alpha_drop, proj_drop,
                           out_drop, drop_path_rate, _MAX_ATOM_TYPE, _AVG_DEGREE, _AVG_NUM_NODES)
+        if use_attn_head:  # one more attention layer reads the energy out of the equivariant feature [ref: :196-207]
+            self.head = GraphAttention(self.irreps_feature, self.irreps_node_attr, self.irreps_edge_attr,
+                                       Irreps("1x0e"), self.fc_neurons, self.irreps_head, num_heads, irreps_pre_attn,
+                                       rescale_degree, nonlinear_message, alpha_drop, proj_drop)
+            self.apply(self._init_weights)
+
+    def _attention_heads(self):
+        return [self.head] if self.use_attn_head else []
 
     def _make_rbf(self):
         if self.basis_type == "gaussian":
@@ -127,3 +133,13 @@ def graph_attention_transformer_nonlinear_exp_l3_md17(irreps_in, radius, num_bas
     return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref,
                  irreps_node_embedding="128x0e+64x1e+64x2e+32x3e", irreps_sh="1x0e+1x1e+1x2e+1x3e",
                  irreps_head="32x0e+16x1e+16x2e+8x3e", irreps_mlp_mid="384x0e+192x1e+192x2e+96x3e")
+
+
+@register_model
+def graph_attention_transformer_nonlinear_attn_exp_l3_md17(irreps_in, radius, num_basis=128, atomref=None,
+                                                           task_mean=None, task_std=None, **kwargs):
+    """[ref: nets/graph_attention_transformer_md17.py:445-462] L_max = 3 feature, GraphAttention energy head"""
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref,
+                 irreps_node_embedding="128x0e+64x1e+64x2e+32x3e", irreps_sh="1x0e+1x1e+1x2e+1x3e",
+                 irreps_feature="128x0e+64x1e+64x2e+32x3e", irreps_head="32x0e+16x1e+16x2e+8x3e",
+                 irreps_mlp_mid="384x0e+192x1e+192x2e+96x3e", use_attn_head=True)

@@ -5,15 +5,17 @@ The reference registers the class in ocpmodels' registry as "graph_attention_tra
 (`oc20_graph_attention_transformer`) and accepts any object with the same attributes
 (`pos, batch, atomic_numbers, tags, natoms`, and for periodic inputs either `cell` -- the neighbour search then runs
 on the GPU (`EdgeGraph.from_radius_pbc`, the `otf_graph=True` path of the YAML config) -- or a precomputed `edge_index` +
-per-edge Cartesian `offsets` as radius_graph_pbc / get_pbc_distances produce upstream).  Auxiliary IS2RS head, attention head and
-atom-edge attributes are not used by the `l1_256_nonlinear` config and are rejected.
+per-edge Cartesian `offsets` as radius_graph_pbc / get_pbc_distances produce upstream).  The auxiliary IS2RS head
+(`use_auxiliary_task`, the `*_aux_*` configs), the attention head (`use_attention_head`) and per-graph stochastic depth
+(`drop_path_rate`) are built as upstream; atom-edge attributes and node attributes are used by no shipped config and are
+rejected.
 """
 import torch
 
 from ..graph import EdgeGraph
 from ..irreps import Irreps
-from .graph_attention_transformer import _Trunk
-from .layers import NodeEmbeddingNetwork
+from .graph_attention_transformer import _RESCALE, _Trunk
+from .layers import Activation, GraphAttention, LinearRS, NodeEmbeddingNetwork
 from .registry import register_model
 
 _MAX_ATOM_TYPE = 84
@@ -33,8 +35,8 @@ class GraphAttentionTransformerOC20(_Trunk):
                  auxiliary_head_dropout=True, use_attention_head=False, otf_graph=False, use_pbc=True,
                  max_neighbors=50):
         super().__init__()
-        if use_node_attr or use_atom_edge_attr or use_auxiliary_task or use_attention_head:
-            raise NotImplementedError("only the plain IS2RE energy head is on the MI355X hot path")
+        if use_node_attr or use_atom_edge_attr:
+            raise NotImplementedError("node attributes / atom-edge attributes are used by no shipped OC20 config")
         self.otf_graph, self.use_pbc, self.max_neighbors = otf_graph, use_pbc, max_neighbors
         self.basis_type = "gaussian"
         self._build_trunk(irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius,
@@ -42,6 +44,31 @@ class GraphAttentionTransformerOC20(_Trunk):
                           rescale_degree, nonlinear_message, irreps_mlp_mid, norm_layer, alpha_drop, proj_drop,
                           out_drop, drop_path_rate, _MAX_ATOM_TYPE, _AVG_DEGREE, _AVG_NUM_NODES)
         self.tag_embed = NodeEmbeddingNetwork(self.irreps_node_embedding, _NUM_TAGGED)
+        # energy head on the scalar channels of the feature [ref: :169-179]
+        scalars = Irreps([(m, ir) for m, ir in self.irreps_feature if ir.l == 0 and ir.p == 1])
+        self.head = torch.nn.Sequential(LinearRS(self.irreps_feature, scalars, rescale=_RESCALE),
+                                        Activation(scalars, kind="silu"),
+                                        LinearRS(scalars, Irreps("1x0e")))
+        self.use_auxiliary_task, self.use_attention_head = use_auxiliary_task, use_attention_head
+        irreps_aux = Irreps("1x1e")  # the SO(3) variants carry no 1o feature [ref: :185-187]
+        head_drop = alpha_drop if auxiliary_head_dropout else 0.0
+
+        def attention(irreps_out):
+            return GraphAttention(self.irreps_feature, self.irreps_node_attr, self.irreps_edge_attr, irreps_out,
+                                  self.fc_neurons, self.irreps_head, num_heads, irreps_pre_attn, rescale_degree,
+                                  nonlinear_message, alpha_drop=head_drop, proj_drop=0.0)
+        if use_auxiliary_task and not use_attention_head:  # IS2RS auxiliary head [ref: :182-194]
+            self.auxiliary_head = attention(irreps_aux)
+        if use_attention_head:  # GraphAttention for energy (and auxiliary vectors) + linear skip [ref: :196-208]
+            irreps_out = Irreps("1x0e") + irreps_aux if use_auxiliary_task else Irreps("1x0e")
+            self.head = attention(irreps_out)
+            self.head_skip_connect = LinearRS(self.irreps_feature, irreps_out)
+        self.apply(self._init_weights)
+
+    def _attention_heads(self):
+        if self.use_attention_head:
+            return [self.head]
+        return [self.auxiliary_head] if self.use_auxiliary_task else []
 
     def forward(self, data):
         pos = data.pos.to(torch.float32).contiguous()
@@ -65,7 +92,17 @@ class GraphAttentionTransformerOC20(_Trunk):
                 graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=self.max_neighbors)
         atom_embedding, _, _ = self.atom_embed(data.atomic_numbers.long())
         tag_embedding, _, _ = self.tag_embed(data.tags.long())
-        return self._trunk_forward(atom_embedding + tag_embedding, pos, graph, offsets)
+        node_features, ectx = self._trunk_features(atom_embedding + tag_embedding, pos, graph, offsets)
+        scatter = lambda t: self.scale_scatter(t, graph.mol_ptr, graph.batch, graph.num_graphs)  # noqa: E731
+        if self.use_attention_head:  # [ref: :352-366]
+            outputs = self.head(node_features, ectx=ectx) + self.head_skip_connect(node_features)
+            if self.use_auxiliary_task:
+                return scatter(outputs.narrow(1, 0, 1).contiguous()), outputs.narrow(1, 1, 3)
+            return scatter(outputs)
+        energy = scatter(self.head(node_features))
+        if self.use_auxiliary_task:  # [ref: :372-379]
+            return energy, self.auxiliary_head(node_features, ectx=ectx)
+        return energy
 
     @property
     def num_params(self):
@@ -90,3 +127,28 @@ def oc20_l1_256_nonlinear(**over):
                drop_path_rate=0.0, otf_graph=True, use_pbc=True, max_neighbors=500)
     cfg.update(over)
     return GraphAttentionTransformerOC20(None, None, 1, **cfg)
+
+
+@register_model
+def oc20_l1_256_nonlinear_aux(**over):
+    """oc20/configs/is2re/all/graph_attention_transformer/l1_256_nonlinear_aux_g@2_local.yml: feature with l=1 channels,
+    IS2RS auxiliary head, stochastic depth 0.05.  Returns (energy [B,1], per-node vectors [N,3])."""
+    cfg = dict(irreps_feature="512x0e+256x1e", drop_path_rate=0.05, use_auxiliary_task=True)
+    cfg.update(over)
+    return oc20_l1_256_nonlinear(**cfg)
+
+
+@register_model
+def oc20_l1_256_blocks18_nonlinear_aux(**over):
+    """oc20/configs/is2re/all/graph_attention_transformer/l1_256_blocks@18_nonlinear_aux_g@4_local.yml"""
+    cfg = dict(num_layers=18)
+    cfg.update(over)
+    return oc20_l1_256_nonlinear_aux(**cfg)
+
+
+@register_model
+def oc20_l1_256(**over):
+    """oc20/configs/is2re/all/graph_attention_transformer/l1_256_g@2_local.yml (linear messages)"""
+    cfg = dict(nonlinear_message=False, num_layers=8)
+    cfg.update(over)
+    return oc20_l1_256_nonlinear(**cfg)

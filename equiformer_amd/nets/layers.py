@@ -596,13 +596,32 @@ class FeedForwardNetwork(nn.Module):
         return self.fctp_2(self.fctp_1(node_input, node_attr), node_attr)
 
 
+class GraphDropPath(nn.Module):
+    """Per-graph stochastic depth [ref: nets/drop.py:45-61]: in training every graph of the batch keeps the branch with
+    probability 1 - drop_prob (scaled by 1/keep), decided by one draw per graph from torch's CPU generator (fp64, the
+    stream the fp64 oracle consumes under the same seed); the row scaling itself is eqf_segment_scale."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x, graph):
+        if not self.drop_prob or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        r = torch.rand((graph.num_graphs, 1), dtype=torch.float64)
+        s = ((keep + r).floor_() / keep).to(torch.float32).view(-1)
+        return ops.segment_scale(x, s.to(x.device, non_blocking=True), graph.batch)
+
+    def extra_repr(self):
+        return "drop_prob={}".format(self.drop_prob)
+
+
 class TransBlock(nn.Module):
     def __init__(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_output, fc_neurons,
                  irreps_head, num_heads, irreps_pre_attn=None, rescale_degree=False, nonlinear_message=False,
                  alpha_drop=0.1, proj_drop=0.1, drop_path_rate=0.0, irreps_mlp_mid=None, norm_layer="layer"):
         super().__init__()
-        if drop_path_rate != 0.0:
-            raise NotImplementedError("drop_path_rate != 0 is not used by any registered model")
         self.irreps_node_input = Irreps(irreps_node_input)
         self.irreps_node_attr = Irreps(irreps_node_attr)
         self.irreps_edge_attr = Irreps(irreps_edge_attr)
@@ -613,7 +632,7 @@ class TransBlock(nn.Module):
         self.ga = GraphAttention(self.irreps_node_input, self.irreps_node_attr, self.irreps_edge_attr,
                                  self.irreps_node_input, fc_neurons, irreps_head, num_heads, irreps_pre_attn,
                                  rescale_degree, nonlinear_message, alpha_drop, proj_drop)
-        self.drop_path = None
+        self.drop_path = GraphDropPath(drop_path_rate) if drop_path_rate > 0.0 else None
         self.norm_2 = norm(self.irreps_node_input)
         self.ffn = FeedForwardNetwork(self.irreps_node_input, self.irreps_node_attr, self.irreps_node_output,
                                       self.irreps_mlp_mid, proj_drop)
@@ -623,9 +642,12 @@ class TransBlock(nn.Module):
                                                                    self.irreps_node_output, bias=True,
                                                                    rescale=_RESCALE)
 
+    def _drop(self, x, ectx):
+        return x if self.drop_path is None else self.drop_path(x, ectx.graph)
+
     def forward(self, node_input, node_attr=None, ectx=None, **kwargs):
-        node_output = node_input + self.ga(self.norm_1(node_input), ectx=ectx)
-        node_features = self.ffn(self.norm_2(node_output), node_attr)
+        node_output = node_input + self._drop(self.ga(self.norm_1(node_input), ectx=ectx), ectx)
+        node_features = self._drop(self.ffn(self.norm_2(node_output), node_attr), ectx)
         if self.ffn_shortcut is not None:
             node_output = self.ffn_shortcut(node_output, node_attr)
         return node_output + node_features
@@ -635,8 +657,8 @@ class TransBlock(nn.Module):
         (node_output, node_features): every residual add then rides on the layer norm that follows it (norm_1 here,
         norm_2, and the next block's norm_1 or the model's final norm) instead of being its own launch."""
         node_input, h = self.norm_1.forward_sum(a, b)
-        node_output, h2 = self.norm_2.forward_sum(node_input, self.ga(h, ectx=ectx))
-        node_features = self.ffn(h2, node_attr)
+        node_output, h2 = self.norm_2.forward_sum(node_input, self._drop(self.ga(h, ectx=ectx), ectx))
+        node_features = self._drop(self.ffn(h2, node_attr), ectx)
         if self.ffn_shortcut is not None:
             node_output = self.ffn_shortcut(node_output, node_attr)
         return node_output, node_features

@@ -997,6 +997,27 @@ def segment_sum(x, ptr, seg_of, nseg, scale=1.0):
     return _SegmentSum.apply(x, ptr, seg_of, nseg, float(scale))
 
 
+class _SegmentScale(Function):
+    @staticmethod
+    def forward(ctx, x, s, seg_of):
+        x = _c(x)
+        _chk(x, s, seg_of)
+        out = torch.empty_like(x)
+        call("eqf_segment_scale", _p(x), _p(s), _p(seg_of), _p(out), x.shape[0], x.shape[1], _stream())
+        ctx.save_for_backward(s, seg_of)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, seg_of = ctx.saved_tensors
+        return _SegmentScale.apply(dout, s, seg_of), None, None  # linear: its own backward at every order
+
+
+def segment_scale(x, s, seg_of):
+    """out[q] = s[seg_of[q]] * x[q] (s: one non-differentiable factor per segment)."""
+    return _SegmentScale.apply(x, s, seg_of)
+
+
 class _EdgeGeom(Function):
     @staticmethod
     def forward(ctx, pos, offsets, graph, lmax):

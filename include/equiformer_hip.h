@@ -342,6 +342,12 @@ int eqf_segment_sum(const float* x, const int* ptr, const int* perm, float* out,
 int eqf_segment_bcast(const float* x, const int* seg_of, float* out, int rows, int D, float scale,
                       void* stream);
 
+/* out[q,:] = s[seg_of[q]] * x[q,:]  (D % 4 == 0; out may alias x).  Per-graph stochastic depth: s holds 0 or
+ * 1/keep_prob per graph.  Linear in x: its backward is the same call on dy.
+ * [ref: nets/drop.py:45-61 GraphDropPath; nets/graph_attention_transformer.py:652-664] */
+int eqf_segment_scale(const float* x, const float* s, const int* seg_of, float* out, int rows, int D,
+                      void* stream);
+
 /* Depth-wise tensor product, un-fused form (kept as the building block for shapes the fused GEMM
  * does not cover and as its on-device cross-check): out[e, :] per eqf_dtp_paths.  w may be NULL.
  * [ref: DepthwiseTensorProduct + o3.TensorProduct('uvu'), nets/graph_attention_transformer.py:157-183] */

@@ -454,7 +454,8 @@ class TransBlock(nn.Module):
                  irreps_head, num_heads, irreps_pre_attn=None, rescale_degree=False, nonlinear_message=False,
                  alpha_drop=0.1, proj_drop=0.1, drop_path_rate=0.0, irreps_mlp_mid=None, norm_layer="layer"):
         super().__init__()
-        assert norm_layer == "layer" and drop_path_rate == 0.0
+        assert norm_layer == "layer"
+        self.drop_path_rate = drop_path_rate
         irreps_node_input, irreps_node_output = Irreps(irreps_node_input), Irreps(irreps_node_output)
         self.norm_1 = EquivariantLayerNormV2(irreps_node_input)
         self.ga = GraphAttention(irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_input, fc_neurons,
@@ -467,9 +468,18 @@ class TransBlock(nn.Module):
             self.ffn_shortcut = FullyConnectedTensorProductRescale(irreps_node_input, irreps_node_attr,
                                                                    irreps_node_output, bias=True, rescale=_RESCALE)
 
-    def forward(self, x, node_attr, edge_src, edge_dst, edge_attr, edge_scalars):
-        out = x + self.ga(self.norm_1(x), edge_src, edge_dst, edge_attr, edge_scalars)
-        f = self.ffn(self.norm_2(out), node_attr)
+    def _drop_path(self, x, batch):
+        """GraphDropPath [ref: nets/drop.py:13-29,45-61]: one keep/drop draw per graph, kept rows scaled by 1/keep."""
+        if self.drop_path_rate == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_path_rate
+        r = torch.rand((int(batch.max()) + 1, 1), dtype=torch.float64)
+        return x * ((keep + r).floor_() / keep).to(x.dtype)[batch]
+
+    def forward(self, x, node_attr, edge_src, edge_dst, edge_attr, edge_scalars, batch=None):
+        # [ref: nets/graph_attention_transformer.py:637-668]
+        out = x + self._drop_path(self.ga(self.norm_1(x), edge_src, edge_dst, edge_attr, edge_scalars), batch)
+        f = self._drop_path(self.ffn(self.norm_2(out), node_attr), batch)
         if self.ffn_shortcut is not None:
             out = self.ffn_shortcut(out, node_attr)
         return out + f
@@ -520,7 +530,8 @@ class _Base(nn.Module):
 
     def _build(self, irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius, number_of_basis,
                basis_type, fc_neurons, irreps_feature, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
-               nonlinear_message, irreps_mlp_mid, alpha_drop, max_atom_type, avg_degree, avg_nodes):
+               nonlinear_message, irreps_mlp_mid, alpha_drop, max_atom_type, avg_degree, avg_nodes,
+               drop_path_rate=0.0):
         self.max_radius, self.number_of_basis = max_radius, number_of_basis
         self.irreps_node_embedding = Irreps(irreps_node_embedding)
         self.irreps_feature = Irreps(irreps_feature)
@@ -543,11 +554,12 @@ class _Base(nn.Module):
             out = self.irreps_node_embedding if i != num_layers - 1 else self.irreps_feature
             self.blocks.append(TransBlock(self.irreps_node_embedding, irreps_node_attr, self.irreps_edge_attr, out,
                                           self.fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
-                                          nonlinear_message, alpha_drop, 0.0, 0.0, irreps_mlp_mid, "layer"))
+                                          nonlinear_message, alpha_drop, 0.0, drop_path_rate, irreps_mlp_mid, "layer"))
         self.norm = EquivariantLayerNormV2(self.irreps_feature)
-        self.head = nn.Sequential(LinearRS(self.irreps_feature, self.irreps_feature, rescale=_RESCALE),
-                                  Activation(self.irreps_feature, [torch.nn.functional.silu]),
-                                  LinearRS(self.irreps_feature, Irreps("1x0e"), rescale=_RESCALE))
+        if all(ir.l == 0 for _, ir in self.irreps_feature):  # otherwise the subclass brings its own head (OC20)
+            self.head = nn.Sequential(LinearRS(self.irreps_feature, self.irreps_feature, rescale=_RESCALE),
+                                      Activation(self.irreps_feature, [torch.nn.functional.silu]),
+                                      LinearRS(self.irreps_feature, Irreps("1x0e"), rescale=_RESCALE))
         self.scale_scatter = ScaledScatter(avg_nodes)
         self.apply(self._init_weights)
 
@@ -561,15 +573,19 @@ class _Base(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def _trunk(self, node_embedding, pos, batch, edge_src, edge_dst, edge_vec, num_graphs):
+        x, edge_sh, edge_emb = self._features(node_embedding, batch, edge_src, edge_dst, edge_vec)
+        out = self.head(x, edge_src, edge_dst, edge_sh, edge_emb) if isinstance(self.head, GraphAttention) else self.head(x)
+        return self.scale_scatter(out, batch, num_graphs)
+
+    def _features(self, node_embedding, batch, edge_src, edge_dst, edge_vec):
         edge_sh = spherical_harmonics(self.lmax_sh, edge_vec, normalize=True, normalization="component")
         edge_len = edge_vec.norm(dim=1)
         edge_emb = self.rbf(edge_len)
         x = node_embedding + self.edge_deg_embed(node_embedding, edge_sh, edge_emb, edge_src, edge_dst)
         node_attr = torch.ones_like(x[:, 0:1])
         for blk in self.blocks:
-            x = blk(x, node_attr, edge_src, edge_dst, edge_sh, edge_emb)
-        x = self.head(self.norm(x))
-        return self.scale_scatter(x, batch, num_graphs)
+            x = blk(x, node_attr, edge_src, edge_dst, edge_sh, edge_emb, batch)
+        return self.norm(x), edge_sh, edge_emb
 
 
 _QM9_AVG_NUM_NODES = 18.03065905448718
@@ -609,13 +625,18 @@ class GraphAttentionTransformerMD17(_Base):
                  norm_layer="layer", alpha_drop=0.2, proj_drop=0.0, out_drop=0.0, drop_path_rate=0.0, mean=None,
                  std=None, scale=None, atomref=None):
         super().__init__()
-        assert not use_attn_head
         self.task_mean, self.task_std, self.scale = mean, std, scale
         self.register_buffer("atomref", atomref)
         self._build(irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius, number_of_basis,
                     basis_type, list(fc_neurons), irreps_feature, irreps_head, num_heads, irreps_pre_attn,
                     rescale_degree, nonlinear_message, irreps_mlp_mid, alpha_drop, 64, _QM9_AVG_DEGREE,
                     _QM9_AVG_NUM_NODES)
+        self.use_attn_head = use_attn_head
+        if use_attn_head:  # [ref: nets/graph_attention_transformer_md17.py:196-207, :304-308]
+            self.head = GraphAttention(self.irreps_feature, irreps_node_attr, self.irreps_edge_attr, Irreps("1x0e"),
+                                       self.fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
+                                       nonlinear_message, alpha_drop, proj_drop)
+            self.apply(self._init_weights)
 
     @torch.enable_grad()
     def forward(self, node_atom, pos, batch):
@@ -631,22 +652,45 @@ class GraphAttentionTransformerMD17(_Base):
 
 
 class GraphAttentionTransformerOC20(_Base):
-    """Energy path only; edges (edge_index + per-edge Cartesian offsets) are supplied by the caller, which is what
-    ocpmodels' radius_graph_pbc/get_pbc_distances produce upstream (graph_attention_transformer_oc20.py:267-302)."""
+    """Edges (edge_index + per-edge Cartesian offsets) are supplied by the caller, which is what ocpmodels'
+    radius_graph_pbc/get_pbc_distances produce upstream (graph_attention_transformer_oc20.py:267-302).  Returns the
+    energy, or (energy, per-node auxiliary vectors) with use_auxiliary_task (IS2RS head, :182-208, :352-381)."""
 
     def __init__(self, num_atoms=None, bond_feat_dim=None, num_targets=1, irreps_node_embedding="256x0e+128x1e",
                  num_layers=6, irreps_node_attr="1x0e", use_node_attr=False, irreps_sh="1x0e+1x1e", max_radius=6.0,
                  number_of_basis=128, fc_neurons=[64, 64], irreps_feature="512x0e", irreps_head="32x0e+16x1e",
                  num_heads=8, irreps_pre_attn=None, rescale_degree=False, nonlinear_message=False,
                  irreps_mlp_mid="768x0e+384x1e", norm_layer="layer", alpha_drop=0.2, proj_drop=0.0, out_drop=0.0,
-                 drop_path_rate=0.0, max_neighbors=50, **unused):
+                 drop_path_rate=0.0, use_auxiliary_task=False, auxiliary_head_dropout=True, use_attention_head=False,
+                 max_neighbors=50, **unused):
         super().__init__()
         assert not use_node_attr
         self.max_neighbors = max_neighbors
         self._build(irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius, number_of_basis,
                     "gaussian", list(fc_neurons), irreps_feature, irreps_head, num_heads, irreps_pre_attn,
-                    rescale_degree, nonlinear_message, irreps_mlp_mid, alpha_drop, 84, 23.395238876342773, 77.81317)
+                    rescale_degree, nonlinear_message, irreps_mlp_mid, alpha_drop, 84, 23.395238876342773, 77.81317,
+                    drop_path_rate=drop_path_rate)
         self.tag_embed = NodeEmbeddingNetwork(self.irreps_node_embedding, 3)
+        # the OC20 energy head reads the scalar channels of the feature only [ref: :169-179]
+        scalars = Irreps([(m, ir) for m, ir in self.irreps_feature if ir.l == 0 and ir.p == 1])
+        self.head = nn.Sequential(LinearRS(self.irreps_feature, scalars, rescale=_RESCALE),
+                                  Activation(scalars, [torch.nn.functional.silu]),
+                                  LinearRS(scalars, Irreps("1x0e")))
+        self.use_auxiliary_task, self.use_attention_head = use_auxiliary_task, use_attention_head
+        irreps_aux = Irreps("1x1e")  # SO(3) variants carry no 1o [ref: :185-187]
+        head_drop = alpha_drop if auxiliary_head_dropout else 0.0
+
+        def attention(irreps_out):
+            return GraphAttention(self.irreps_feature, irreps_node_attr, self.irreps_edge_attr, irreps_out,
+                                  self.fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
+                                  nonlinear_message, alpha_drop=head_drop, proj_drop=0.0)
+        if use_auxiliary_task and not use_attention_head:
+            self.auxiliary_head = attention(irreps_aux)
+        if use_attention_head:
+            irreps_out = Irreps("1x0e") + irreps_aux if use_auxiliary_task else Irreps("1x0e")
+            self.head = attention(irreps_out)
+            self.head_skip_connect = LinearRS(self.irreps_feature, irreps_out)
+        self.apply(self._init_weights)
 
     def forward(self, atomic_numbers, tags, pos, batch, edge_index=None, offsets=None):
         if edge_index is None:
@@ -658,7 +702,16 @@ class GraphAttentionTransformerOC20(_Base):
             edge_vec = edge_vec + offsets
         emb, _, _ = self.atom_embed(atomic_numbers.long())
         tag, _, _ = self.tag_embed(tags.long())
-        return self._trunk(emb + tag, pos, batch, edge_src, edge_dst, edge_vec, int(batch.max()) + 1)
+        num_graphs = int(batch.max()) + 1
+        x, edge_sh, edge_emb = self._features(emb + tag, batch, edge_src, edge_dst, edge_vec)
+        if self.use_attention_head:
+            out = self.head(x, edge_src, edge_dst, edge_sh, edge_emb) + self.head_skip_connect(x)
+            energy = self.scale_scatter(out[:, 0:1], batch, num_graphs)
+            return (energy, out[:, 1:4]) if self.use_auxiliary_task else energy
+        energy = self.scale_scatter(self.head(x), batch, num_graphs)
+        if self.use_auxiliary_task:
+            return energy, self.auxiliary_head(x, edge_src, edge_dst, edge_sh, edge_emb)
+        return energy
 
 
 # ---------------------------------------------------------------------------- factories (registered names)
@@ -706,8 +759,8 @@ def oc20_l1_256_nonlinear(**kwargs):
     """oc20/configs/is2re/all/graph_attention_transformer/l1_256_nonlinear_g@2_local.yml model section."""
     cfg = dict(irreps_node_embedding="256x0e+128x1e", num_layers=6, irreps_sh="1x0e+1x1e", max_radius=5.0,
                number_of_basis=128, fc_neurons=[64, 64], irreps_feature="512x0e", irreps_head="32x0e+16x1e",
-               num_heads=8, nonlinear_message=True, irreps_mlp_mid="768x0e+384x1e", alpha_drop=0.2,
-               max_neighbors=500)
+               num_heads=8, irreps_pre_attn="256x0e+128x1e", nonlinear_message=True,
+               irreps_mlp_mid="768x0e+384x1e", alpha_drop=0.2, max_neighbors=500)
     cfg.update(kwargs)
     return GraphAttentionTransformerOC20(**cfg)
 

@@ -172,7 +172,7 @@ def test_oc20_energy_parity():
     assert _rel(y2, yr2) < 1e-4
 
 
-@pytest.mark.parametrize("small", ["SMALL_L2", "SMALL_L3"])
+@pytest.mark.parametrize("small", ["SMALL_L2", "SMALL_L3", "SMALL_L3_ATTN_HEAD"])
 def test_md17_force_loss_second_order_gradients(small):
     """Training on the force loss (reference: main_md17.py:384-390 with create_graph forces): gradients of
     L = <a, E> + <B, F> w.r.t. every parameter against the fp64 oracle's double backward, reduced MD17-L2 model with
@@ -185,7 +185,11 @@ def test_md17_force_loss_second_order_gradients(small):
     from equiformer_amd.nets.graph_attention_transformer_md17 import GraphAttentionTransformerMD17
     from equiformer_amd.synthetic import md17_aspirin_batch
     dev = _dev()
-    kw = dict(irreps_in="64x0e", max_radius=5.0, number_of_basis=32, basis_type="exp", **getattr(mg, small))
+    if small == "SMALL_L3_ATTN_HEAD":  # ..._nonlinear_attn_exp_l3_md17 [ref: :445-462]: equivariant feature + GraphAttention head
+        cfg = dict(mg.SMALL_L3, irreps_feature=mg.SMALL_L3["irreps_node_embedding"], use_attn_head=True)
+    else:
+        cfg = getattr(mg, small)
+    kw = dict(irreps_in="64x0e", max_radius=5.0, number_of_basis=32, basis_type="exp", **cfg)
     ref = fill_deterministic(onets.GraphAttentionTransformerMD17(**kw), 12).double().train()
     mod = fill_deterministic(GraphAttentionTransformerMD17(**kw), 12).to(dev).train()
     d = md17_aspirin_batch(2, seed=3)

@@ -71,6 +71,35 @@ def test_registry_and_factories():
         nets.model_entrypoint("graph_attention_transformer_nonlinear_l2_e3")("5x0e", 5.0)
 
 
+def test_oc20_and_md17_head_variants_build_with_reference_keys():
+    """Auxiliary / attention heads and stochastic depth (OC20 *_aux_* configs, MD17 ..._attn_exp_l3_md17): same parameter
+    names and shapes as the oracle's restatement of the reference, heads included in the radial bank."""
+    from equiformer_amd import nets
+    from equiformer_amd.nets.layers import GraphDropPath
+    from oracle import nets as onets
+    over = dict(num_layers=2)
+    m = nets.model_entrypoint("oc20_l1_256_nonlinear_aux")(**over)
+    o = onets.oc20_l1_256_nonlinear(irreps_feature="512x0e+256x1e", use_auxiliary_task=True, drop_path_rate=0.05, **over)
+    assert {k: v.shape for k, v in m.state_dict().items()} == {k: v.shape for k, v in o.state_dict().items()}
+    assert isinstance(m.blocks[0].drop_path, GraphDropPath) and m.blocks[0].drop_path.drop_prob == 0.05
+    assert m.head[0].layout_out.dim == 512 and "auxiliary_head.alpha_dot" in m.state_dict()
+    assert len(m._radial_bank().modules) == 1 + 2 + 1  # degree embedding, blocks, auxiliary head
+    m = nets.model_entrypoint("oc20_graph_attention_transformer")(
+        name="graph_attention_transformer", num_layers=1, use_attention_head=True, use_auxiliary_task=True)
+    assert m.head_skip_connect.layout_out.dim == 4 and not hasattr(m, "auxiliary_head")
+    assert nets.model_entrypoint("oc20_l1_256")(num_layers=1).blocks[0].ga.nonlinear_message is False
+    assert len(nets.model_entrypoint("oc20_l1_256_blocks18_nonlinear_aux")().blocks) == 18
+    m = nets.model_entrypoint("graph_attention_transformer_nonlinear_attn_exp_l3_md17")("64x0e", 5.0, num_basis=32)
+    o = onets.GraphAttentionTransformerMD17(
+        irreps_in="64x0e", irreps_node_embedding="128x0e+64x1e+64x2e+32x3e", irreps_sh="1x0e+1x1e+1x2e+1x3e",
+        max_radius=5.0, number_of_basis=32, basis_type="exp", irreps_feature="128x0e+64x1e+64x2e+32x3e",
+        irreps_head="32x0e+16x1e+16x2e+8x3e", num_heads=4, nonlinear_message=True,
+        irreps_mlp_mid="384x0e+192x1e+192x2e+96x3e", use_attn_head=True, alpha_drop=0.0)
+    assert {k: v.shape for k, v in m.state_dict().items()} == {k: v.shape for k, v in o.state_dict().items()}
+    with pytest.raises(NotImplementedError):
+        nets.model_entrypoint("oc20_l1_256_nonlinear")(use_atom_edge_attr=True)
+
+
 @pytest.mark.parametrize("name,kw,count", [
     ("graph_attention_transformer_nonlinear_l2", dict(irreps_in="5x0e", radius=5.0), 3531715),
     ("graph_attention_transformer_nonlinear_exp_l2_md17", dict(irreps_in="64x0e", radius=5.0, num_basis=32), 3496001),

@@ -122,6 +122,39 @@ def test_kat6_kat8_equivariance_and_permutation():
     assert (y - m(None, pos[p], batch[p], z[p])).abs().max() < 1e-10
 
 
+def test_oc20_heads_are_equivariant_and_drop_path_is_per_graph():
+    """OC20 auxiliary / attention heads of the oracle [ref: graph_attention_transformer_oc20.py:182-208, :352-381]: the
+    energy is rotation invariant, the per-node auxiliary output rotates as a vector; GraphDropPath [ref: nets/drop.py:
+    45-61] zeroes whole graphs and rescales the kept ones by 1/keep."""
+    g = torch.Generator().manual_seed(6)
+    cfg = dict(irreps_node_embedding="64x0e+32x1e", num_layers=2, irreps_sh="1x0e+1x1e", max_radius=5.0,
+               number_of_basis=16, fc_neurons=[16, 16], irreps_feature="64x0e+32x1e", irreps_head="16x0e+8x1e",
+               num_heads=4, nonlinear_message=True, irreps_mlp_mid="64x0e+32x1e", alpha_drop=0.0)
+    N = 14
+    pos = torch.rand(N, 3, generator=g, dtype=torch.float64) * 4.0
+    batch = torch.tensor([0] * 7 + [1] * 7)
+    z = torch.randint(1, 80, (N,), generator=g)
+    tags = torch.randint(0, 3, (N,), generator=g)
+    R = _rot(g)
+    for heads in (dict(use_auxiliary_task=True), dict(use_attention_head=True, use_auxiliary_task=True)):
+        torch.manual_seed(0)
+        m = nets.GraphAttentionTransformerOC20(**cfg, **heads).double().eval()
+        e, a = m(z, tags, pos, batch)
+        e2, a2 = m(z, tags, pos @ R.T, batch)
+        assert e.shape == (2, 1) and a.shape == (N, 3) and a.abs().max() > 1e-3
+        assert (e - e2).abs().max() < 1e-10 and (a2 - a @ R.T).abs().max() < 1e-10
+    torch.manual_seed(0)
+    m = nets.GraphAttentionTransformerOC20(**cfg, drop_path_rate=0.5).double()
+    blk = m.blocks[0].train()
+    x = torch.randn(N, 5, generator=g, dtype=torch.float64)
+    torch.manual_seed(3)
+    y = blk._drop_path(x, batch)
+    torch.manual_seed(3)
+    keep = torch.floor(0.5 + torch.rand((2, 1), dtype=torch.float64))
+    assert torch.equal(y, x * (keep / 0.5)[batch])
+    assert torch.equal(blk.eval()._drop_path(x, batch), x)
+
+
 def test_kat6_kat7_md17_forces():
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(5)
