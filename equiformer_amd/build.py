@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libequiformer_hip.so")
-SOURCES = ["gemm.hip", "sfc.hip", "rowops.hip", "edge.hip", "graph.hip", "second.hip", "optim.hip", "prof.hip"]
+SOURCES = ["gemm.hip", "sfc.hip", "rowops.hip", "edge.hip", "graph.hip", "second.hip", "dpattn.hip", "optim.hip", "prof.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 

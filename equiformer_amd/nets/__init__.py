@@ -6,3 +6,4 @@ from .registry import model_entrypoint, register_model, list_models  # noqa: F40
 from .graph_attention_transformer import *  # noqa: F401,F403
 from .graph_attention_transformer_md17 import *  # noqa: F401,F403
 from .graph_attention_transformer_oc20 import *  # noqa: F401,F403
+from .dp_attention_transformer import *  # noqa: F401,F403

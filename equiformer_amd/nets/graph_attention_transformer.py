@@ -61,7 +61,7 @@ class _Trunk(nn.Module):
         self.blocks = nn.ModuleList()
         for i in range(num_layers):
             out = self.irreps_node_embedding if i != num_layers - 1 else self.irreps_feature
-            self.blocks.append(TransBlock(
+            self.blocks.append(self._block_cls(
                 irreps_node_input=self.irreps_node_embedding, irreps_node_attr=self.irreps_node_attr,
                 irreps_edge_attr=self.irreps_edge_attr, irreps_node_output=out, fc_neurons=self.fc_neurons,
                 irreps_head=self.irreps_head, num_heads=num_heads, irreps_pre_attn=irreps_pre_attn,
@@ -119,13 +119,14 @@ class _Trunk(nn.Module):
         bank = self.__dict__.get("_bank")
         if bank is None:
             mods = [self.edge_deg_embed.rad]
-            for ga in [blk.ga for blk in self.blocks] + self._attention_heads():
-                mods.append(ga.sep_act.dtp_rad if ga.nonlinear_message else ga.sep.dtp_rad)
+            for attn in [blk.attention for blk in self.blocks] + self._attention_heads():
+                mods.append(attn.radial_module())
             bank = RadialBank(mods)
             self.__dict__["_bank"] = bank  # plain attribute (not a sub-module, not copied into state_dict)
         return bank if (bank.ok and self.use_radial_bank) else None
 
     use_radial_bank = True
+    _block_cls = TransBlock
 
     def _attention_heads(self):
         """GraphAttention modules that read the final features (OC20 auxiliary / attention heads); none by default."""

@@ -87,8 +87,9 @@ def _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, **over):
               irreps_pre_attn=None, rescale_degree=False, nonlinear_message=True,
               irreps_mlp_mid="384x0e+192x1e+96x2e", norm_layer="layer", alpha_drop=0.0, proj_drop=0.0, out_drop=0.0,
               drop_path_rate=0.0, mean=task_mean, std=task_std, scale=None, atomref=atomref)
+    cls = over.pop("cls", GraphAttentionTransformerMD17)
     kw.update(over)
-    return GraphAttentionTransformerMD17(**kw)
+    return cls(**kw)
 
 
 @register_model

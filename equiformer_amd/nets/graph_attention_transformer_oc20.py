@@ -54,9 +54,8 @@ class GraphAttentionTransformerOC20(_Trunk):
         head_drop = alpha_drop if auxiliary_head_dropout else 0.0
 
         def attention(irreps_out):
-            return GraphAttention(self.irreps_feature, self.irreps_node_attr, self.irreps_edge_attr, irreps_out,
-                                  self.fc_neurons, self.irreps_head, num_heads, irreps_pre_attn, rescale_degree,
-                                  nonlinear_message, alpha_drop=head_drop, proj_drop=0.0)
+            return self._head_attention(irreps_out, num_heads, irreps_pre_attn, rescale_degree, nonlinear_message,
+                                        head_drop)
         if use_auxiliary_task and not use_attention_head:  # IS2RS auxiliary head [ref: :182-194]
             self.auxiliary_head = attention(irreps_aux)
         if use_attention_head:  # GraphAttention for energy (and auxiliary vectors) + linear skip [ref: :196-208]
@@ -64,6 +63,11 @@ class GraphAttentionTransformerOC20(_Trunk):
             self.head = attention(irreps_out)
             self.head_skip_connect = LinearRS(self.irreps_feature, irreps_out)
         self.apply(self._init_weights)
+
+    def _head_attention(self, irreps_out, num_heads, irreps_pre_attn, rescale_degree, nonlinear_message, alpha_drop):
+        return GraphAttention(self.irreps_feature, self.irreps_node_attr, self.irreps_edge_attr, irreps_out,
+                              self.fc_neurons, self.irreps_head, num_heads, irreps_pre_attn, rescale_degree,
+                              nonlinear_message, alpha_drop=alpha_drop, proj_drop=0.0)
 
     def _attention_heads(self):
         if self.use_attention_head:

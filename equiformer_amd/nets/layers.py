@@ -541,6 +541,10 @@ class GraphAttention(nn.Module):
         attn = ops.attn_aggregate(logit, value, g, self.num_heads, self.heads_layout, drop_p, seed)
         return self.proj(attn)
 
+    def radial_module(self):
+        """The RadialProfile evaluated on the shared radial basis (a member of the model's RadialBank)."""
+        return self.sep_act.dtp_rad if self.nonlinear_message else self.sep.dtp_rad
+
     def _nonlinear_message(self, message, ectx):
         sa = self.sep_act
         table = sa.dtp.table
@@ -575,6 +579,65 @@ class GraphAttention(nn.Module):
         b = sep.lin._bias()
         return ops.sep_fctp(message, M, weight, w_main, b.index_select(0, self._idx_value), self.lin_sfc_spec,
                             weight2=w_alpha, bias2=b.index_select(0, self._idx_alpha))
+
+
+class DotProductAttention(nn.Module):
+    """Scaled dot-product attention over irreps heads [ref: nets/dp_attention_transformer.py:68-160].  Queries: one
+    LinearRS on the destination node; keys and values: ONE fused SeparableFCTP on the merged message producing 2H heads
+    per edge (first H = keys), split by eqf_kv_split; logits with the ScaleFactor (:45-66) folded in by
+    eqf_dp_logits_*; softmax + dropout + aggregation by the eqf_attn_aggregate_* kernels GraphAttention uses."""
+
+    def __init__(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_output, fc_neurons,
+                 irreps_head, num_heads, irreps_pre_attn=None, rescale_degree=False, alpha_drop=0.1, proj_drop=0.1):
+        super().__init__()
+        self.irreps_node_input = Irreps(irreps_node_input)
+        self.irreps_node_attr = Irreps(irreps_node_attr)
+        self.irreps_edge_attr = Irreps(irreps_edge_attr)
+        self.irreps_node_output = Irreps(irreps_node_output)
+        self.irreps_pre_attn = self.irreps_node_input if irreps_pre_attn is None else Irreps(irreps_pre_attn)
+        self.irreps_head = Irreps(irreps_head)
+        self.num_heads = num_heads
+        self.rescale_degree = rescale_degree
+        if rescale_degree:
+            raise NotImplementedError("rescale_degree=True is not used by any registered model")
+        if proj_drop != 0.0:
+            raise NotImplementedError("proj_drop != 0 is not used by any registered model")
+        if [ir.l for _, ir in self.irreps_head] != sorted({ir.l for _, ir in self.irreps_head}):
+            raise NotImplementedError("irreps_head must list each degree once, in ascending order")
+        irreps_attn_heads = _simplified_sorted(self.irreps_head * num_heads)
+        self.query = LinearRS(self.irreps_node_input, irreps_attn_heads)
+        irreps_kv_heads = _simplified_sorted(self.irreps_head * num_heads * 2)
+        self.merge_src = LinearRS(self.irreps_node_input, self.irreps_pre_attn, bias=True)
+        self.merge_dst = LinearRS(self.irreps_node_input, self.irreps_pre_attn, bias=False)
+        self.key_value = SeparableFCTP(self.irreps_pre_attn, self.irreps_edge_attr, irreps_kv_heads, fc_neurons,
+                                       use_activation=False, norm_layer=None)
+        self.heads_layout = RowLayout(irreps_attn_heads)
+        self.alpha_drop = float(alpha_drop)
+        self.alpha_dropout = nn.Dropout(alpha_drop) if alpha_drop != 0.0 else None  # marker module (no params)
+        self.proj = LinearRS(irreps_attn_heads, self.irreps_node_output)
+        self.proj_drop = None
+        self.use_fused = True
+
+    def radial_module(self):
+        return self.key_value.dtp_rad
+
+    def forward(self, node_input, node_attr=None, edge_src=None, edge_dst=None, edge_attr=None, edge_scalars=None,
+                batch=None, ectx=None, **kwargs):
+        g, H = ectx.graph, self.num_heads
+        q = self.query(node_input)
+        message = ops.gather_add(self.merge_src(node_input), self.merge_dst(node_input), g)
+        kv = self.key_value(message, ectx, use_fused=self.use_fused)
+        k, v = ops.kv_split(kv, H, self.heads_layout)
+        logit = ops.dp_logits(q, k, g, H, self.heads_layout)
+        drop_p, seed = 0.0, 0
+        if self.training and self.alpha_drop > 0.0:
+            drop_p = self.alpha_drop
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+        attn = ops.attn_aggregate(logit, v, g, H, self.heads_layout, drop_p, seed)
+        return self.proj(attn)
+
+    def extra_repr(self):
+        return "rescale_degree={}".format(self.rescale_degree)
 
 
 class FeedForwardNetwork(nn.Module):
@@ -629,9 +692,8 @@ class TransBlock(nn.Module):
         self.irreps_mlp_mid = Irreps(irreps_mlp_mid) if irreps_mlp_mid is not None else self.irreps_node_input
         norm = get_norm_layer(norm_layer)
         self.norm_1 = norm(self.irreps_node_input)
-        self.ga = GraphAttention(self.irreps_node_input, self.irreps_node_attr, self.irreps_edge_attr,
-                                 self.irreps_node_input, fc_neurons, irreps_head, num_heads, irreps_pre_attn,
-                                 rescale_degree, nonlinear_message, alpha_drop, proj_drop)
+        setattr(self, self.attn_name, self._make_attention(fc_neurons, irreps_head, num_heads, irreps_pre_attn,
+                                                           rescale_degree, nonlinear_message, alpha_drop, proj_drop))
         self.drop_path = GraphDropPath(drop_path_rate) if drop_path_rate > 0.0 else None
         self.norm_2 = norm(self.irreps_node_input)
         self.ffn = FeedForwardNetwork(self.irreps_node_input, self.irreps_node_attr, self.irreps_node_output,
@@ -642,11 +704,23 @@ class TransBlock(nn.Module):
                                                                    self.irreps_node_output, bias=True,
                                                                    rescale=_RESCALE)
 
+    attn_name = "ga"  # the attribute (= state_dict prefix) the attention module lives under
+
+    def _make_attention(self, fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree, nonlinear_message,
+                        alpha_drop, proj_drop):
+        return GraphAttention(self.irreps_node_input, self.irreps_node_attr, self.irreps_edge_attr,
+                              self.irreps_node_input, fc_neurons, irreps_head, num_heads, irreps_pre_attn,
+                              rescale_degree, nonlinear_message, alpha_drop, proj_drop)
+
+    @property
+    def attention(self):
+        return getattr(self, self.attn_name)
+
     def _drop(self, x, ectx):
         return x if self.drop_path is None else self.drop_path(x, ectx.graph)
 
     def forward(self, node_input, node_attr=None, ectx=None, **kwargs):
-        node_output = node_input + self._drop(self.ga(self.norm_1(node_input), ectx=ectx), ectx)
+        node_output = node_input + self._drop(self.attention(self.norm_1(node_input), ectx=ectx), ectx)
         node_features = self._drop(self.ffn(self.norm_2(node_output), node_attr), ectx)
         if self.ffn_shortcut is not None:
             node_output = self.ffn_shortcut(node_output, node_attr)
@@ -657,11 +731,22 @@ class TransBlock(nn.Module):
         (node_output, node_features): every residual add then rides on the layer norm that follows it (norm_1 here,
         norm_2, and the next block's norm_1 or the model's final norm) instead of being its own launch."""
         node_input, h = self.norm_1.forward_sum(a, b)
-        node_output, h2 = self.norm_2.forward_sum(node_input, self._drop(self.ga(h, ectx=ectx), ectx))
+        node_output, h2 = self.norm_2.forward_sum(node_input, self._drop(self.attention(h, ectx=ectx), ectx))
         node_features = self._drop(self.ffn(h2, node_attr), ectx)
         if self.ffn_shortcut is not None:
             node_output = self.ffn_shortcut(node_output, node_attr)
         return node_output, node_features
+
+
+class DPTransBlock(TransBlock):
+    """[ref: nets/dp_attention_transformer.py:163-252] the pre-norm block with DotProductAttention under `dpa`."""
+    attn_name = "dpa"
+
+    def _make_attention(self, fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree, nonlinear_message,
+                        alpha_drop, proj_drop):
+        return DotProductAttention(self.irreps_node_input, self.irreps_node_attr, self.irreps_edge_attr,
+                                   self.irreps_node_input, fc_neurons, irreps_head, num_heads, irreps_pre_attn,
+                                   rescale_degree, alpha_drop, proj_drop)
 
 
 class NodeEmbeddingNetwork(nn.Module):

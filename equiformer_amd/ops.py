@@ -1838,3 +1838,121 @@ class _AttnAggregateBwd(Function):
 
 def attn_aggregate(logit, value, graph, H, layout, drop_p=0.0, seed=0):
     return _AttnAggregate.apply(logit, value, graph, H, layout, float(drop_p), int(seed))
+
+
+# ------------------------------------------------------------------------------------------------- dot-product attention
+class _KvSplit(Function):
+    """kv [E, 2D] -> (k, v) [E, D] each (rows follow the H-head irreps `layout`); linear, backward = _KvMerge."""
+
+    @staticmethod
+    def forward(ctx, kv, H, layout):
+        kv = _c(kv)
+        _chk(kv)
+        E = kv.shape[0]
+        assert kv.shape[1] == 2 * layout.dim
+        k = torch.empty((E, layout.dim), device=kv.device, dtype=torch.float32)
+        v = torch.empty_like(k)
+        call("eqf_kv_split", _p(kv), _p(k), _p(v), E, H, layout.c_ref, _stream())
+        ctx.args = (H, layout)
+        return k, v
+
+    @staticmethod
+    def backward(ctx, dk, dv):
+        H, layout = ctx.args
+        return _KvMerge.apply(dk, dv, H, layout), None, None
+
+
+class _KvMerge(Function):
+    @staticmethod
+    def forward(ctx, k, v, H, layout):
+        ref = k if k is not None else v
+        k = _c(k) if k is not None else None
+        v = _c(v) if v is not None else None
+        _chk(k, v)
+        kv = torch.empty((ref.shape[0], 2 * layout.dim), device=ref.device, dtype=torch.float32)
+        call("eqf_kv_merge", _p(k), _p(v), _p(kv), ref.shape[0], H, layout.c_ref, _stream())
+        ctx.args = (H, layout)
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv):
+        H, layout = ctx.args
+        k, v = _KvSplit.apply(dkv, H, layout)
+        return k, v, None, None
+
+
+def kv_split(kv, H, layout):
+    return _KvSplit.apply(kv, H, layout)
+
+
+def _dp_logits_fwd(q, k, graph, H, layout):
+    logit = torch.empty((k.shape[0], H), device=k.device, dtype=torch.float32)
+    call("eqf_dp_logits_fwd", _p(q), _p(k), _p(graph.dst), _p(logit), k.shape[0], H, layout.c_ref, _stream())
+    return logit
+
+
+def _dp_logits_bwd(q, k, dlogit, graph, H, layout, want_q, want_k):
+    dq = torch.empty((graph.N, layout.dim), device=dlogit.device, dtype=torch.float32) if want_q else None
+    dk = torch.empty((dlogit.shape[0], layout.dim), device=dlogit.device, dtype=torch.float32) if want_k else None
+    call("eqf_dp_logits_bwd", _p(q) if want_k else None, _p(k) if want_q else None, _p(dlogit), _p(graph.row_ptr), _p(dq),
+         _p(dk), graph.N, H, layout.c_ref, _stream())
+    return dq, dk
+
+
+class _DpLogits(Function):
+    """logit[e,h] = <scaled q[dst[e]], k[e]> over the channels of head h [ref: nets/dp_attention_transformer.py:131-146]."""
+
+    @staticmethod
+    def forward(ctx, q, k, graph, H, layout):
+        q, k = _c(q), _c(k)
+        _chk(q, k)
+        ctx.save_for_backward(q, k)
+        ctx.args = (graph, H, layout)
+        return _dp_logits_fwd(q, k, graph, H, layout)
+
+    @staticmethod
+    def backward(ctx, dlogit):
+        q, k = ctx.saved_tensors
+        graph, H, layout = ctx.args
+        if torch.is_grad_enabled():  # create_graph
+            dq, dk = _DpLogitsBwd.apply(q, k, dlogit, graph, H, layout)
+            return dq, dk, None, None, None
+        dlogit = _c(dlogit)
+        _chk(dlogit)
+        dq, dk = _dp_logits_bwd(q, k, dlogit, graph, H, layout, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dq, dk, None, None, None
+
+
+class _DpLogitsBwd(Function):
+    """(dq, dk) as a differentiable op of (q, k, dlogit).  The logits are bilinear, so with cotangents (cq, ck):
+    g_dlogit = L(cq, k) + L(q, ck),  g_q = dq-map(dlogit, ck),  g_k = dk-map(dlogit, cq) -- the first-order kernels."""
+
+    @staticmethod
+    def forward(ctx, q, k, dlogit, graph, H, layout):
+        dlogit = _c(dlogit)
+        _chk(dlogit)
+        ctx.save_for_backward(q, k, dlogit)
+        ctx.args = (graph, H, layout)
+        return _dp_logits_bwd(q, k, dlogit, graph, H, layout, True, True)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, cq, ck):
+        q, k, dlogit = ctx.saved_tensors
+        graph, H, layout = ctx.args
+        cq = _c(cq) if cq is not None else None
+        ck = _c(ck) if ck is not None else None
+        _chk(cq, ck)
+        g_q = g_k = g_dl = None
+        if cq is not None:
+            g_dl = _dp_logits_fwd(cq, k, graph, H, layout)
+            g_k = _dp_logits_bwd(cq, None, dlogit, graph, H, layout, False, True)[1]
+        if ck is not None:
+            t = _dp_logits_fwd(q, ck, graph, H, layout)
+            g_dl = t if g_dl is None else g_dl + t
+            g_q = _dp_logits_bwd(None, ck, dlogit, graph, H, layout, True, False)[0]
+        return g_q, g_k, g_dl, None, None, None
+
+
+def dp_logits(q, k, graph, H, layout):
+    return _DpLogits.apply(q, k, graph, H, layout)

@@ -382,6 +382,25 @@ int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* ro
                            const eqf_irreps* irreps, float drop_p, unsigned long long seed,
                            void* stream);
 
+/* ---- dot-product attention (the dp_attention_transformer family) ---------------------------------------------------
+ * `irreps` = the H-head irreps of q / k / v rows (segment mul = H * channels-of-head, channels-of-head % 4 == 0,
+ * H <= 8).  The key/value row of an edge is 2D wide: in every segment [2l+1][2*mul] the first `mul` channels of an m-row
+ * are the H key heads, the last `mul` the H value heads (Vec2AttnHeads(irreps_head, 2H) followed by narrow).
+ * [ref: nets/dp_attention_transformer.py:131-152] */
+/* k[E,D], v[E,D] <- kv[E,2D] */
+int eqf_kv_split(const float* kv, float* k, float* v, int E, int H, const eqf_irreps* irreps, void* stream);
+/* kv[E,2D] <- k, v (either may be NULL = zeros): the backward of eqf_kv_split */
+int eqf_kv_merge(const float* k, const float* v, float* kv, int E, int H, const eqf_irreps* irreps, void* stream);
+/* logit[e,h] = sum over the channels of head h of  scale_l * q[dst[e], .] * k[e, .],
+ * scale_l = 1 / sqrt(num_irreps(head) * (2l+1))  (ScaleFactor, :45-66, applied to q upstream).  D <= 1024. */
+int eqf_dp_logits_fwd(const float* q, const float* k, const int* dst, float* logit, int E, int H,
+                      const eqf_irreps* irreps, void* stream);
+/* dq[N,D] (needs k) and/or dk[E,D] (needs q) written; either output may be NULL.  Edges are dst-sorted (row_ptr), dq is
+ * a segmented reduction without atomics.  The logits are bilinear, so these two entry points also serve the
+ * second-order pass. */
+int eqf_dp_logits_bwd(const float* q, const float* k, const float* d_logit, const int* row_ptr, float* dq, float* dk,
+                      int N, int H, const eqf_irreps* irreps, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Second-derivative entry points (MD17 force-loss training).  The reference takes forces with
  * create_graph=True and back-propagates a loss on them [ref: nets/graph_attention_transformer_md17.py:

@@ -424,6 +424,44 @@ class GraphAttention(nn.Module):
         return self.proj(attn)
 
 
+class DotProductAttention(nn.Module):
+    """Scaled dot-product attention over irreps heads [ref: nets/dp_attention_transformer.py:68-160]: queries from the
+    destination node, keys and values from ONE SeparableFCTP on the merged source/destination message (2H heads, the
+    first H are keys), ScaleFactor (:45-66) on the queries, PyG softmax over incoming edges."""
+
+    def __init__(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_output, fc_neurons,
+                 irreps_head, num_heads, irreps_pre_attn=None, rescale_degree=False, alpha_drop=0.1, proj_drop=0.1):
+        super().__init__()
+        self.irreps_node_input = Irreps(irreps_node_input)
+        self.irreps_pre_attn = self.irreps_node_input if irreps_pre_attn is None else Irreps(irreps_pre_attn)
+        self.irreps_head, self.num_heads = Irreps(irreps_head), num_heads
+        assert not rescale_degree and proj_drop == 0.0
+        heads_all = sort_irreps_even_first(self.irreps_head * num_heads)[0].simplify()
+        self.query = LinearRS(self.irreps_node_input, heads_all)
+        kv_heads = sort_irreps_even_first(self.irreps_head * num_heads * 2)[0].simplify()
+        self.merge_src = LinearRS(self.irreps_node_input, self.irreps_pre_attn, bias=True)
+        self.merge_dst = LinearRS(self.irreps_node_input, self.irreps_pre_attn, bias=False)
+        self.key_value = SeparableFCTP(self.irreps_pre_attn, irreps_edge_attr, kv_heads, fc_neurons, use_activation=False)
+        self.alpha_dropout = nn.Dropout(alpha_drop) if alpha_drop != 0.0 else None
+        self.proj = LinearRS(heads_all, Irreps(irreps_node_output))
+        # ScaleFactor: 1/sqrt(number of irreps of a head) per channel, 1/sqrt(2l+1) per irrep
+        chan = 1.0 / (self.irreps_head.num_irreps ** 0.5)
+        self.register_buffer("_q_scale", torch.cat([torch.full((mul * ir.dim,), chan / ir.dim ** 0.5)
+                                                    for mul, ir in self.irreps_head]), persistent=False)
+
+    def forward(self, node_input, edge_src, edge_dst, edge_attr, edge_scalars):
+        q = vec2heads(self.query(node_input), self.irreps_head, self.num_heads) * self._q_scale.to(node_input.dtype)
+        kv = self.merge_src(node_input)[edge_src] + self.merge_dst(node_input)[edge_dst]
+        kv = vec2heads(self.key_value(kv, edge_attr, edge_scalars), self.irreps_head, self.num_heads * 2)
+        k, v = kv[:, :self.num_heads], kv[:, self.num_heads:]
+        alpha = torch.einsum("bik,bik->bi", q[edge_dst], k)
+        alpha = segment_softmax(alpha, edge_dst, node_input.shape[0]).unsqueeze(-1)
+        if self.alpha_dropout is not None:
+            alpha = self.alpha_dropout(alpha)
+        attn = heads2vec(scatter_sum(v * alpha, edge_dst, node_input.shape[0]), self.irreps_head)
+        return self.proj(attn)
+
+
 class FCTPSwishGate(FullyConnectedTensorProductRescale):
     """FullyConnectedTensorProductRescaleSwishGate (graph_attention_transformer.py:128-154)."""
 
@@ -450,6 +488,8 @@ class FeedForwardNetwork(nn.Module):
 
 
 class TransBlock(nn.Module):
+    attn_name = "ga"
+
     def __init__(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_output, fc_neurons,
                  irreps_head, num_heads, irreps_pre_attn=None, rescale_degree=False, nonlinear_message=False,
                  alpha_drop=0.1, proj_drop=0.1, drop_path_rate=0.0, irreps_mlp_mid=None, norm_layer="layer"):
@@ -458,15 +498,20 @@ class TransBlock(nn.Module):
         self.drop_path_rate = drop_path_rate
         irreps_node_input, irreps_node_output = Irreps(irreps_node_input), Irreps(irreps_node_output)
         self.norm_1 = EquivariantLayerNormV2(irreps_node_input)
-        self.ga = GraphAttention(irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_input, fc_neurons,
-                                 irreps_head, num_heads, irreps_pre_attn, rescale_degree, nonlinear_message,
-                                 alpha_drop, proj_drop)
+        self._make_attention(irreps_node_input, irreps_node_attr, irreps_edge_attr, fc_neurons, irreps_head, num_heads,
+                             irreps_pre_attn, rescale_degree, nonlinear_message, alpha_drop, proj_drop)
         self.norm_2 = EquivariantLayerNormV2(irreps_node_input)
         self.ffn = FeedForwardNetwork(irreps_node_input, irreps_node_attr, irreps_node_output, irreps_mlp_mid, proj_drop)
         self.ffn_shortcut = None
         if irreps_node_input != irreps_node_output:
             self.ffn_shortcut = FullyConnectedTensorProductRescale(irreps_node_input, irreps_node_attr,
                                                                    irreps_node_output, bias=True, rescale=_RESCALE)
+
+    def _make_attention(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, fc_neurons, irreps_head, num_heads,
+                        irreps_pre_attn, rescale_degree, nonlinear_message, alpha_drop, proj_drop):
+        self.ga = GraphAttention(irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_input, fc_neurons,
+                                 irreps_head, num_heads, irreps_pre_attn, rescale_degree, nonlinear_message,
+                                 alpha_drop, proj_drop)
 
     def _drop_path(self, x, batch):
         """GraphDropPath [ref: nets/drop.py:13-29,45-61]: one keep/drop draw per graph, kept rows scaled by 1/keep."""
@@ -478,11 +523,22 @@ class TransBlock(nn.Module):
 
     def forward(self, x, node_attr, edge_src, edge_dst, edge_attr, edge_scalars, batch=None):
         # [ref: nets/graph_attention_transformer.py:637-668]
-        out = x + self._drop_path(self.ga(self.norm_1(x), edge_src, edge_dst, edge_attr, edge_scalars), batch)
+        out = x + self._drop_path(getattr(self, self.attn_name)(self.norm_1(x), edge_src, edge_dst, edge_attr, edge_scalars), batch)
         f = self._drop_path(self.ffn(self.norm_2(out), node_attr), batch)
         if self.ffn_shortcut is not None:
             out = self.ffn_shortcut(out, node_attr)
         return out + f
+
+
+class DPTransBlock(TransBlock):
+    """[ref: nets/dp_attention_transformer.py:163-252] the same pre-norm block with DotProductAttention as `dpa`."""
+    attn_name = "dpa"
+
+    def _make_attention(self, irreps_node_input, irreps_node_attr, irreps_edge_attr, fc_neurons, irreps_head, num_heads,
+                        irreps_pre_attn, rescale_degree, nonlinear_message, alpha_drop, proj_drop):
+        self.dpa = DotProductAttention(irreps_node_input, irreps_node_attr, irreps_edge_attr, irreps_node_input,
+                                       fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree, alpha_drop,
+                                       proj_drop)
 
 
 class NodeEmbeddingNetwork(nn.Module):
@@ -527,6 +583,7 @@ class EdgeDegreeEmbeddingNetwork(nn.Module):
 
 class _Base(nn.Module):
     """Shared trunk of the three model variants."""
+    block_cls = TransBlock
 
     def _build(self, irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius, number_of_basis,
                basis_type, fc_neurons, irreps_feature, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
@@ -552,7 +609,7 @@ class _Base(nn.Module):
         self.blocks = nn.ModuleList()
         for i in range(num_layers):
             out = self.irreps_node_embedding if i != num_layers - 1 else self.irreps_feature
-            self.blocks.append(TransBlock(self.irreps_node_embedding, irreps_node_attr, self.irreps_edge_attr, out,
+            self.blocks.append(self.block_cls(self.irreps_node_embedding, irreps_node_attr, self.irreps_edge_attr, out,
                                           self.fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
                                           nonlinear_message, alpha_drop, 0.0, drop_path_rate, irreps_mlp_mid, "layer"))
         self.norm = EquivariantLayerNormV2(self.irreps_feature)
@@ -681,6 +738,10 @@ class GraphAttentionTransformerOC20(_Base):
         head_drop = alpha_drop if auxiliary_head_dropout else 0.0
 
         def attention(irreps_out):
+            if self.block_cls is DPTransBlock:  # [ref: nets/dp_attention_transformer_oc20.py:146-151]
+                return DotProductAttention(self.irreps_feature, irreps_node_attr, self.irreps_edge_attr, irreps_out,
+                                           self.fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
+                                           alpha_drop, proj_drop=0.0)
             return GraphAttention(self.irreps_feature, irreps_node_attr, self.irreps_edge_attr, irreps_out,
                                   self.fc_neurons, irreps_head, num_heads, irreps_pre_attn, rescale_degree,
                                   nonlinear_message, alpha_drop=head_drop, proj_drop=0.0)
@@ -712,6 +773,21 @@ class GraphAttentionTransformerOC20(_Base):
         if self.use_auxiliary_task:
             return energy, self.auxiliary_head(x, edge_src, edge_dst, edge_sh, edge_emb)
         return energy
+
+
+class DotProductAttentionTransformer(GraphAttentionTransformer):
+    """[ref: nets/dp_attention_transformer.py:255-411] the QM9 model with DPTransBlock in place of TransBlock."""
+    block_cls = DPTransBlock
+
+
+class DotProductAttentionTransformerMD17(GraphAttentionTransformerMD17):
+    """[ref: nets/dp_attention_transformer_md17.py:57-235]"""
+    block_cls = DPTransBlock
+
+
+class DotProductAttentionTransformerOC20(GraphAttentionTransformerOC20):
+    """[ref: nets/dp_attention_transformer_oc20.py:36-347] (no attention head in this family)"""
+    block_cls = DPTransBlock
 
 
 # ---------------------------------------------------------------------------- factories (registered names)
@@ -765,7 +841,31 @@ def oc20_l1_256_nonlinear(**kwargs):
     return GraphAttentionTransformerOC20(**cfg)
 
 
+def dot_product_attention_transformer_l2(irreps_in, radius, num_basis=128, atomref=None, task_mean=None, task_std=None,
+                                         **kwargs):
+    """[ref: nets/dp_attention_transformer.py:414-431]"""
+    return DotProductAttentionTransformer(
+        irreps_in=irreps_in, irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6, irreps_node_attr="1x0e",
+        irreps_sh="1x0e+1x1e+1x2e", max_radius=radius, number_of_basis=num_basis, fc_neurons=[64, 64],
+        irreps_feature="512x0e", irreps_head="32x0e+16x1e+8x2e", num_heads=4, rescale_degree=False,
+        nonlinear_message=False, irreps_mlp_mid="384x0e+192x1e+96x2e", alpha_drop=0.2, mean=task_mean, std=task_std,
+        atomref=atomref)
+
+
+def dot_product_attention_transformer_exp_l2_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                  task_std=None, **kwargs):
+    """[ref: nets/dp_attention_transformer_md17.py:238-254]"""
+    return DotProductAttentionTransformerMD17(
+        irreps_in=irreps_in, irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6, irreps_node_attr="1x0e",
+        irreps_sh="1x0e+1x1e+1x2e", max_radius=radius, number_of_basis=num_basis, fc_neurons=[64, 64],
+        basis_type="exp", irreps_feature="512x0e", irreps_head="32x0e+16x1e+8x2e", num_heads=4, rescale_degree=False,
+        nonlinear_message=False, irreps_mlp_mid="384x0e+192x1e+96x2e", alpha_drop=0.0, mean=task_mean, std=task_std,
+        atomref=atomref)
+
+
 ENTRYPOINTS = {
+    "dot_product_attention_transformer_l2": dot_product_attention_transformer_l2,
+    "dot_product_attention_transformer_exp_l2_md17": dot_product_attention_transformer_exp_l2_md17,
     "graph_attention_transformer_l2": graph_attention_transformer_l2,
     "graph_attention_transformer_nonlinear_l2": graph_attention_transformer_nonlinear_l2,
     "graph_attention_transformer_nonlinear_exp_l2_md17": graph_attention_transformer_nonlinear_exp_l2_md17,

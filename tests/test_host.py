@@ -104,7 +104,9 @@ def test_oc20_and_md17_head_variants_build_with_reference_keys():
     ("graph_attention_transformer_nonlinear_l2", dict(irreps_in="5x0e", radius=5.0), 3531715),
     ("graph_attention_transformer_nonlinear_exp_l2_md17", dict(irreps_in="64x0e", radius=5.0, num_basis=32), 3496001),
     ("graph_attention_transformer_nonlinear_exp_l3_md17", dict(irreps_in="64x0e", radius=5.0, num_basis=32), 5500865),
-    ("oc20_l1_256_nonlinear", dict(), 9123331)])
+    ("oc20_l1_256_nonlinear", dict(), 9123331),
+    ("dot_product_attention_transformer_l2", dict(irreps_in="5x0e", radius=5.0), 3352579),
+    ("dot_product_attention_transformer_exp_l2_md17", dict(irreps_in="64x0e", radius=5.0, num_basis=32), 3316865)])
 def test_parameter_counts_and_state_dict_keys(name, kw, count):
     from equiformer_amd import nets
     from oracle import nets as onets
@@ -118,8 +120,9 @@ def test_parameter_counts_and_state_dict_keys(name, kw, count):
         assert sm[k].shape == so[k].shape, k
     if hasattr(m, "no_weight_decay"):
         nwd = m.no_weight_decay()
-        assert "blocks.0.norm_1.affine_weight" in nwd and "rbf.mean" in nwd or "md17" in name or "oc20" in name
-        assert "blocks.0.ga.sep_act.dtp_rad.net.0.bias" in nwd and "blocks.0.ga.sep_act.dtp_rad.net.0.weight" not in nwd
+        assert "blocks.0.norm_1.affine_weight" in nwd and ("rbf.mean" in nwd or "md17" in name or "oc20" in name)
+        rad = "blocks.0.dpa.key_value.dtp_rad" if "dot_product" in name else "blocks.0.ga.sep_act.dtp_rad"
+        assert rad + ".net.0.bias" in nwd and rad + ".net.0.weight" not in nwd
 
 
 def test_appendix_a_keys_present():
