@@ -269,6 +269,21 @@ __global__ __launch_bounds__(256) void edge_geom_fwd_kernel(const float* __restr
     if (i < S) out[i] = o[i];
 }
 
+// Spherical harmonics of per-node vectors scaled by |v| * norm_scale, rows with keep[n] == 0 zeroed: the force encoding
+// of the DeNS model [ref: nets/equiformer_md17_dens.py:276-289].  Input data, not differentiated.
+__global__ __launch_bounds__(256) void vec_sh_kernel(const float* __restrict__ vec, const unsigned char* __restrict__ keep,
+                                                     int N, int lmax, float norm_scale, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float o[16];
+  const float len = geom_sh<float>(vec[3 * n], vec[3 * n + 1], vec[3 * n + 2], lmax, o);
+  const float f = (keep && !keep[n]) ? 0.f : len * norm_scale;
+  const int S = (lmax + 1) * (lmax + 1);
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < S) out[(long)n * S + i] = o[i] * f;
+}
+
 __global__ __launch_bounds__(256) void edge_geom_bwd_kernel(const float* __restrict__ vec, const float* __restrict__ d_sh,
                                                             const float* __restrict__ d_len, int E, int lmax,
                                                             float* __restrict__ d_vec) {
@@ -552,6 +567,16 @@ int eqf_edge_geom_fwd(const float* pos, const int* src, const int* dst, const fl
   if (E <= 0) return 0;
   hipLaunchKernelGGL(edge_geom_fwd_kernel, dim3(eqf_cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, pos, src, dst,
                      offsets, E, lmax, vec, len, sh);
+  EQF_CHECK_LAUNCH();
+  return 0;
+}
+
+int eqf_vec_sh(const float* vec, const unsigned char* keep, int N, int lmax, float norm_scale, float* out, void* stream) {
+  if (!vec || !out) return EQF_E_BADARG;
+  if (lmax < 0 || lmax > 3) return EQF_E_UNSUPPORTED;
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(vec_sh_kernel, dim3(eqf_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, vec, keep, N, lmax,
+                     norm_scale, out);
   EQF_CHECK_LAUNCH();
   return 0;
 }

@@ -101,6 +101,7 @@ SIGNATURES = {
     "eqf_kv_merge": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "eqf_dp_logits_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "eqf_dp_logits_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
+    "eqf_vec_sh": [c_fp, c_fp, c_int, c_int, _f, c_fp, c_fp],
     "eqf_segment_scale": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp],
     "eqf_dtp_fwd": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_int, c_fp],
     "eqf_dtp_bwd": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, c_fp, c_fp, c_int, c_fp],

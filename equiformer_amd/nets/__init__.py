@@ -7,3 +7,4 @@ from .graph_attention_transformer import *  # noqa: F401,F403
 from .graph_attention_transformer_md17 import *  # noqa: F401,F403
 from .graph_attention_transformer_oc20 import *  # noqa: F401,F403
 from .dp_attention_transformer import *  # noqa: F401,F403
+from .equiformer_md17_dens import *  # noqa: F401,F403

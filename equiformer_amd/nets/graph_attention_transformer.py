@@ -140,7 +140,7 @@ class _Trunk(nn.Module):
             outputs = self.head(node_features)
         return self.scale_scatter(outputs, graph.mol_ptr, graph.batch, graph.num_graphs)
 
-    def _trunk_features(self, node_embedding, pos, graph, offsets=None):
+    def _trunk_features(self, node_embedding, pos, graph, offsets=None, extra=None):
         _, edge_length, edge_sh = ops.edge_geometry(pos, offsets, graph, self.lmax_sh)
         edge_scalars = self.rbf(edge_length)
         # the radial MLPs of all blocks side by side (RadialBank); it has no second-order backward, so it steps aside when
@@ -149,6 +149,8 @@ class _Trunk(nn.Module):
         ectx = EdgeContext(graph, edge_sh, edge_scalars, radial_bank=bank)
         # residual stream kept as a lazy pair (a, b) = a + b: each add is folded into the layer norm that consumes it
         a, b = node_embedding, self.edge_deg_embed(node_embedding, ectx)
+        if extra is not None:  # a further per-node term of the input embedding (DeNS force encoding)
+            b = b + extra
         for blk in self.blocks:
             a, b = blk.forward_pair(a, b, node_attr=None, ectx=ectx)
         _, node_features = self.norm.forward_sum(a, b)

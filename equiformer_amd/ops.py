@@ -1100,6 +1100,21 @@ def edge_geometry(pos, offsets, graph, lmax):
     return _EdgeGeom.apply(pos, offsets, graph, lmax)
 
 
+def vec_sh(vec, keep, lmax, norm_scale):
+    """[N, (lmax+1)^2] spherical harmonics of the rows of `vec`, times |v| * norm_scale, rows with keep == False zeroed
+    (no gradient: the vectors are input data)."""
+    vec = _c(vec.detach().to(torch.float32))
+    _chk(vec)
+    if keep is not None:
+        keep = keep.to(torch.uint8).contiguous()
+        if not keep.is_cuda:
+            raise HipOnlyError("mask on %s" % keep.device)
+    out = torch.empty((vec.shape[0], (lmax + 1) ** 2), device=vec.device, dtype=torch.float32)
+    call("eqf_vec_sh", _p(vec), ctypes.c_void_p(keep.data_ptr()) if keep is not None and keep.numel() else None,
+         vec.shape[0], lmax, float(norm_scale), _p(out), _stream())
+    return out
+
+
 class _RbfGaussian(Function):
     @staticmethod
     def forward(ctx, length, mean, std, weight, bias, cutoff):

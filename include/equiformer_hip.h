@@ -114,6 +114,11 @@ int eqf_csr_by_source(const int* src, const int* row_ptr, const int* mol_ptr, in
 int eqf_edge_geom_fwd(const float* pos, const int* src, const int* dst, const float* offsets, int E,
                       int lmax, float* vec, float* len, float* sh, void* stream);
 
+/* out[n, :] = keep[n] ? |v_n| * norm_scale * Y(v_n / |v_n|) : 0   (component-normalised real spherical harmonics
+ * up to lmax <= 3, [N, (lmax+1)^2]; keep may be NULL = all kept).  The force encoding of the DeNS model (input data,
+ * no gradient).  [ref: nets/equiformer_md17_dens.py:276-289] */
+int eqf_vec_sh(const float* vec, const unsigned char* keep, int N, int lmax, float norm_scale, float* out,
+               void* stream);
 /* d_vec[E,3] from d_sh[E,(lmax+1)^2] (may be NULL) and d_len[E] (may be NULL). */
 int eqf_edge_geom_bwd(const float* vec, const float* d_sh, const float* d_len, int E, int lmax,
                       float* d_vec, void* stream);

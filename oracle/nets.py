@@ -634,11 +634,13 @@ class _Base(nn.Module):
         out = self.head(x, edge_src, edge_dst, edge_sh, edge_emb) if isinstance(self.head, GraphAttention) else self.head(x)
         return self.scale_scatter(out, batch, num_graphs)
 
-    def _features(self, node_embedding, batch, edge_src, edge_dst, edge_vec):
+    def _features(self, node_embedding, batch, edge_src, edge_dst, edge_vec, extra=None):
         edge_sh = spherical_harmonics(self.lmax_sh, edge_vec, normalize=True, normalization="component")
         edge_len = edge_vec.norm(dim=1)
         edge_emb = self.rbf(edge_len)
         x = node_embedding + self.edge_deg_embed(node_embedding, edge_sh, edge_emb, edge_src, edge_dst)
+        if extra is not None:
+            x = x + extra
         node_attr = torch.ones_like(x[:, 0:1])
         for blk in self.blocks:
             x = blk(x, node_attr, edge_src, edge_dst, edge_sh, edge_emb, batch)
@@ -773,6 +775,69 @@ class GraphAttentionTransformerOC20(_Base):
         if self.use_auxiliary_task:
             return energy, self.auxiliary_head(x, edge_src, edge_dst, edge_sh, edge_emb)
         return energy
+
+
+class Equiformer_MD17_DeNS(_Base):
+    """[ref: nets/equiformer_md17_dens.py:55-354] MD17 trunk + force encoding of the uncorrupted structure in the input
+    embedding + scalar-channel energy head + GraphAttention head predicting the position noise of corrupted atoms."""
+
+    def __init__(self, irreps_in="64x0e", irreps_equivariant_inputs="1x0e+1x1e+1x2e",
+                 irreps_node_embedding="128x0e+64x1e+32x2e", num_layers=6, irreps_node_attr="1x0e",
+                 irreps_sh="1x0e+1x1e+1x2e", max_radius=5.0, number_of_basis=32, basis_type="exp", fc_neurons=[64, 64],
+                 irreps_feature="512x0e+256x1e+128x2e", irreps_head="32x0e+16x1e+8x2e", num_heads=4,
+                 irreps_pre_attn="128x0e+64x1e+32x2e", rescale_degree=False, nonlinear_message=True,
+                 irreps_mlp_mid="128x0e+64x1e+32x2e", norm_layer="layer", alpha_drop=0.0, proj_drop=0.0, out_drop=0.0,
+                 drop_path_rate=0.0, mean=None, std=None, scale=None, atomref=None, use_force_encoding=True):
+        super().__init__()
+        self.task_mean, self.task_std, self.scale = mean, std, scale
+        self.register_buffer("atomref", atomref)
+        self.use_force_encoding = use_force_encoding
+        self.irreps_eq_in = Irreps(irreps_equivariant_inputs)
+        self._build(irreps_node_embedding, num_layers, irreps_node_attr, irreps_sh, max_radius, number_of_basis,
+                    basis_type, list(fc_neurons), irreps_feature, irreps_head, num_heads, irreps_pre_attn,
+                    rescale_degree, nonlinear_message, irreps_mlp_mid, alpha_drop, 64, _QM9_AVG_DEGREE,
+                    _QM9_AVG_NUM_NODES, drop_path_rate=drop_path_rate)
+        if hasattr(self, "head"):
+            del self.head
+        self.force_embed = LinearRS(self.irreps_eq_in, self.irreps_node_embedding, rescale=_RESCALE)
+        scalars = Irreps([(m, ir) for m, ir in self.irreps_feature if ir.l == 0 and ir.p == 1])
+        self.energy_head = nn.Sequential(LinearRS(self.irreps_feature, scalars, rescale=_RESCALE),
+                                         Activation(scalars, [torch.nn.functional.silu]),
+                                         LinearRS(scalars, Irreps("1x0e"), rescale=_RESCALE))
+        self.denoising_pos_head = GraphAttention(self.irreps_feature, irreps_node_attr, self.irreps_edge_attr,
+                                                 Irreps("1x1e"), self.fc_neurons, irreps_head, num_heads,
+                                                 irreps_pre_attn, rescale_degree, nonlinear_message, alpha_drop, proj_drop)
+        self.apply(self._init_weights)
+
+    @torch.enable_grad()
+    def forward(self, data):
+        node_atom, batch = data.z, data.batch
+        pos = data.pos.requires_grad_(True)
+        edge_src, edge_dst = radius_graph(pos, self.max_radius, batch, 1000)
+        edge_vec = pos[edge_src] - pos[edge_dst]
+        emb, _, _ = self.atom_embed(node_atom)
+        if hasattr(data, "force") and self.use_force_encoding:
+            force_sh = spherical_harmonics(self.irreps_eq_in.lmax, data.force.to(pos.dtype), normalize=True,
+                                           normalization="component")
+            force_sh = force_sh * data.noise_mask.to(pos.dtype).view(-1, 1)
+            force_sh = force_sh * (data.force.to(pos.dtype).norm(dim=1, keepdim=True) / math.sqrt(3.0))
+        else:
+            force_sh = torch.zeros((pos.shape[0], self.irreps_eq_in.dim), dtype=pos.dtype)
+        x, edge_sh, edge_emb = self._features(emb, batch, edge_src, edge_dst, edge_vec, extra=self.force_embed(force_sh))
+        energy = self.energy_head(x)
+        if hasattr(data, "denoising_mask") and not self.use_force_encoding:
+            energy = energy * (~data.denoising_mask).to(energy.dtype).view(-1, 1)
+        energy = self.scale_scatter(energy, batch, int(batch.max()) + 1)
+        if self.scale is not None:
+            energy = self.scale * energy
+        forces = -1 * torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), create_graph=True)[0]
+        if not hasattr(data, "noise_mask"):
+            return energy, forces
+        den = self.denoising_pos_head(x, edge_src, edge_dst, edge_sh, edge_emb)
+        out = torch.where(data.noise_mask.view(-1, 1), den, forces)
+        if not self.use_force_encoding:
+            out = out * (~data.denoising_pos_mask).to(out.dtype).view(-1, 1)
+        return energy, out
 
 
 class DotProductAttentionTransformer(GraphAttentionTransformer):

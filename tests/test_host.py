@@ -98,6 +98,17 @@ def test_oc20_and_md17_head_variants_build_with_reference_keys():
     assert {k: v.shape for k, v in m.state_dict().items()} == {k: v.shape for k, v in o.state_dict().items()}
     with pytest.raises(NotImplementedError):
         nets.model_entrypoint("oc20_l1_256_nonlinear")(use_atom_edge_attr=True)
+    # DeNS: module (= parameter) order of the reference, names shared with the oracle
+    m = nets.model_entrypoint("equiformer_md17_dens_l2")(num_layers=1)
+    assert [n for n, _ in m.named_children()] == ["atom_embed", "rbf", "edge_deg_embed", "force_embed", "blocks", "norm",
+                                                  "energy_head", "scale_scatter", "denoising_pos_head"]
+    o = onets.Equiformer_MD17_DeNS(
+        num_layers=1, irreps_mlp_mid="384x0e+192x1e+96x2e", irreps_head="32x0e+16x1e+8x2e")
+    assert {k: v.shape for k, v in m.state_dict().items()} == {k: v.shape for k, v in o.state_dict().items()}
+    assert len(nets.model_entrypoint("equiformer_md17_dens_l3")(num_layers=1).denoising_pos_head.heads_layout.segs) == 4
+    for name in ("dot_product_attention_transformer_exp_l3_md17", "oc20_dp_l1_256", "oc20_dp_attention_transformer",
+                 "equiformer_md17_dens"):
+        assert callable(nets.model_entrypoint(name))
 
 
 @pytest.mark.parametrize("name,kw,count", [
