@@ -26,12 +26,15 @@ SegTab make_segtab(const eqf_irreps& ir) {
   for (int s = 0; s < ir.nseg; ++s) {
     t.off[s] = off;
     t.mul[s] = ir.mul[s];
-    t.l[s] = ir.l[s];
+    // "l == 0" below means an invariant scalar (0e): mean subtraction and bias.  A pseudo-scalar segment (0o, E(3) models)
+    // is normalised like any l > 0 segment [ref: nets/layer_norm.py EquivariantLayerNormV2: `ir.l == 0 and ir.p == 1`]
+    const bool scalar = ir.l[s] == 0 && !ir.odd[s];
+    t.l[s] = (ir.l[s] == 0 && ir.odd[s]) ? -1 : ir.l[s];
     t.len[s] = ir.mul[s] * (2 * ir.l[s] + 1);
     t.woff[s] = w;
-    t.boff[s] = (ir.l[s] == 0) ? b : -1;
+    t.boff[s] = scalar ? b : -1;
     w += ir.mul[s];
-    if (ir.l[s] == 0) b += ir.mul[s];
+    if (scalar) b += ir.mul[s];
     off += t.len[s];
   }
   t.D = off;

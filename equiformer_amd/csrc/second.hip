@@ -176,7 +176,7 @@ SegTab2 make_segtab2(const eqf_irreps& ir) {
   t.nseg = ir.nseg;
   int off = 0, w = 0;
   for (int s = 0; s < ir.nseg; ++s) {
-    t.off[s] = off, t.mul[s] = ir.mul[s], t.l[s] = ir.l[s];
+    t.off[s] = off, t.mul[s] = ir.mul[s], t.l[s] = (ir.l[s] == 0 && ir.odd[s]) ? -1 : ir.l[s];  // 0 = invariant scalar
     t.len[s] = ir.mul[s] * (2 * ir.l[s] + 1);
     t.woff[s] = w;
     w += ir.mul[s];

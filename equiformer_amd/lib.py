@@ -11,14 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libequiformer_hip.so")
 
 EQF_MAX_SEG = 8
-EQF_MAX_PATHS = 64
+EQF_MAX_PATHS = 72
 
 c_fp = ctypes.c_void_p  # device pointers travel as opaque addresses
 c_int = ctypes.c_int
 
 
 class EqfIrreps(ctypes.Structure):
-    _fields_ = [("nseg", c_int), ("l", c_int * EQF_MAX_SEG), ("mul", c_int * EQF_MAX_SEG)]
+    _fields_ = [("nseg", c_int), ("l", c_int * EQF_MAX_SEG), ("mul", c_int * EQF_MAX_SEG), ("odd", c_int * EQF_MAX_SEG)]
 
 
 class EqfRows(ctypes.Structure):
@@ -179,8 +179,8 @@ def prof_report():
     return out
 
 
-def make_irreps(segments):
-    """segments: iterable of (mul, l)."""
+def make_irreps(segments, parities=None):
+    """segments: iterable of (mul, l); parities: +1 / -1 per segment (default: all even)."""
     segments = list(segments)
     if len(segments) > EQF_MAX_SEG:
         raise ValueError("too many irreps segments")
@@ -188,4 +188,5 @@ def make_irreps(segments):
     s.nseg = len(segments)
     for i, (mul, l) in enumerate(segments):
         s.l[i], s.mul[i] = int(l), int(mul)
+        s.odd[i] = 1 if parities is not None and parities[i] == -1 else 0
     return s

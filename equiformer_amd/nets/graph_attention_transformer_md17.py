@@ -144,3 +144,32 @@ def graph_attention_transformer_nonlinear_attn_exp_l3_md17(irreps_in, radius, nu
                  irreps_node_embedding="128x0e+64x1e+64x2e+32x3e", irreps_sh="1x0e+1x1e+1x2e+1x3e",
                  irreps_feature="128x0e+64x1e+64x2e+32x3e", irreps_head="32x0e+16x1e+16x2e+8x3e",
                  irreps_mlp_mid="384x0e+192x1e+192x2e+96x3e", use_attn_head=True)
+
+
+_E3_L2 = dict(irreps_node_embedding="128x0e+32x0o+32x1e+32x1o+16x2e+16x2o", irreps_sh="1x0e+1x1o+1x2e",
+              irreps_head="32x0e+8x0o+8x1e+8x1o+4x2e+4x2o", irreps_mlp_mid="384x0e+96x0o+96x1e+96x1o+48x2e+48x2o")
+_E3_L3 = dict(irreps_node_embedding="128x0e+64x0o+32x1e+32x1o+32x2e+32x2o+16x3e+16x3o", irreps_sh="1x0e+1x1o+1x2e+1x3o",
+              irreps_head="32x0e+16x0o+8x1e+8x1o+8x2e+8x2o+4x3e+4x3o",
+              irreps_mlp_mid="384x0e+192x0o+96x1e+96x1o+96x2e+96x2o+48x3e+48x3o")
+
+
+@register_model
+def graph_attention_transformer_nonlinear_l2_e3_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                     task_std=None, **kwargs):
+    """[ref: nets/graph_attention_transformer_md17.py:368-385] E(3) irreps (parity-aware), Gaussian basis, alpha_drop 0.2"""
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, basis_type="gaussian", alpha_drop=0.2,
+                 **_E3_L2)
+
+
+@register_model
+def graph_attention_transformer_nonlinear_exp_l3_e3_md17(irreps_in, radius, num_basis=128, atomref=None, task_mean=None,
+                                                         task_std=None, **kwargs):
+    """[ref: nets/graph_attention_transformer_md17.py:465-482]"""
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, **_E3_L3)
+
+
+@register_model
+def graph_attention_transformer_nonlinear_bessel_l3_e3_md17(irreps_in, radius, num_basis=128, atomref=None,
+                                                            task_mean=None, task_std=None, **kwargs):
+    """[ref: nets/graph_attention_transformer_md17.py:503-519]"""
+    return _md17(irreps_in, radius, num_basis, task_mean, task_std, atomref, basis_type="bessel", **_E3_L3)

@@ -156,3 +156,13 @@ def oc20_l1_256(**over):
     cfg = dict(nonlinear_message=False, num_layers=8)
     cfg.update(over)
     return oc20_l1_256_nonlinear(**cfg)
+
+
+@register_model
+def oc20_l1_256_e3_nonlinear(**over):
+    """oc20/configs/is2re/all/graph_attention_transformer/l1_256_e3_nonlinear_g@2_local.yml (E(3) irreps)"""
+    cfg = dict(irreps_node_embedding="256x0e+64x0o+64x1e+64x1o", irreps_sh="1x0e+1x1o",
+               irreps_head="32x0e+8x0o+8x1e+8x1o", irreps_pre_attn="256x0e+64x0o+64x1e+64x1o",
+               irreps_mlp_mid="768x0e+192x0o+192x1e+192x1o")
+    cfg.update(over)
+    return oc20_l1_256_nonlinear(**cfg)

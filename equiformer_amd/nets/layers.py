@@ -82,8 +82,8 @@ class FullyConnectedTensorProductRescale(nn.Module):
 
     @staticmethod
     def _is_layout(irreps):
-        ls = [ir.l for _, ir in irreps]
-        return ls == sorted(set(ls))
+        keys = [(ir.l, -ir.p) for _, ir in irreps]
+        return keys == sorted(set(keys))
 
     def _bias(self):
         return self.bias[0] if len(self.bias) > 0 else None
@@ -110,7 +110,7 @@ class Activation(nn.Module):
     def __init__(self, irreps_in, acts=None, kind="silu"):
         super().__init__()
         self.irreps_in = self.irreps_out = Irreps(irreps_in)
-        assert all(ir.l == 0 for _, ir in self.irreps_in)
+        assert all(ir.l == 0 and ir.p == 1 for _, ir in self.irreps_in)  # SiLU is neither even nor odd: 0e only
         self.kind = kind
         self.cst = {"silu": so3.C_SILU}[kind]
 
@@ -389,9 +389,9 @@ class SeparableFCTP(nn.Module):
             # row (path, channel) of the stacked lin weight -> index of its shared DTP weight
             idx = []
             t = self.dtp.table
-            for l3 in sorted({p["l3"] for p in t.paths}):
+            for k3 in sorted({(p["l3"], -p["p3"]) for p in t.paths}):
                 for p in t.paths:
-                    if p["l3"] == l3:
+                    if (p["l3"], -p["p3"]) == k3:
                         idx.extend(range(p["w_off"], p["w_off"] + p["mul"]))
             self.register_buffer("_row_to_w", torch.tensor(idx, dtype=torch.long), persistent=False)
             # element of the flat lin weight -> index of the shared DTP weight scaling its row

@@ -270,8 +270,8 @@ class LinearSpec:
         self.in_layout, self.out_layout = in_layout, out_layout
         self.pairs = []  # (l, in_off, K, out_off, N, w_off)
         w_off = 0
-        for (K, l), in_off in zip(in_layout.segs, in_layout.offsets):
-            j = out_layout.seg_index(l)
+        for (K, l), par, in_off in zip(in_layout.segs, in_layout.par, in_layout.offsets):
+            j = out_layout.seg_index(l, par)  # a scalar second operand couples equal degree AND parity only
             if j is None:
                 continue
             N = out_layout.segs[j][0]
@@ -280,8 +280,7 @@ class LinearSpec:
         self.weight_numel = w_off
         self.out_covered = len(self.pairs) == len(out_layout.segs)
         self.in_covered = len(self.pairs) == len(in_layout.segs)
-        self.bias_dim = out_layout.mul_of(0)
-        self.fan_in = {l: K for (l, _, K, _, _, _) in self.pairs}
+        self.bias_dim = out_layout.mul_of(0)  # bias on 0e only
 
 
 def _gemm_group(descs, st):
@@ -1367,17 +1366,75 @@ class _Dtp(Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
         x, coupling, w = ctx.saved_tensors
+        if torch.is_grad_enabled():  # create_graph (forces of the E(3) models, which run the un-fused product)
+            dx, dM, dw = _DtpBwd.apply(x, coupling, w, dout, ctx.table)
+            return dx, dM, dw, None
         dout = _c(dout)
         _chk(dout)
-        E = x.shape[0]
-        dx = torch.empty_like(x) if ctx.table.in_covered else _zeros_like(x)
-        dw = torch.empty_like(w) if (w is not None and ctx.needs_input_grad[2]) else None
-        dM = torch.empty_like(coupling) if ctx.needs_input_grad[1] else None
-        call("eqf_dtp_bwd", _p(x), _p(coupling), _p(w), ctx.table.c_ref, _p(dout), _p(dx), _p(dw), _p(dM), E, _stream())
+        dx, dM, dw = _dtp_bwd(x, coupling, w, dout, ctx.table, ctx.needs_input_grad[1],
+                              w is not None and ctx.needs_input_grad[2])
         return dx, dM, dw, None
+
+
+def _dtp_fwd(x, coupling, w, table):
+    out = torch.empty((x.shape[0], table.layout_out.dim), device=x.device, dtype=torch.float32)
+    call("eqf_dtp_fwd", _p(x), _p(coupling), _p(w), table.c_ref, _p(out), x.shape[0], _stream())
+    return out
+
+
+def _dtp_bwd(x, coupling, w, dout, table, want_M=True, want_w=True, want_x=True):
+    dx = (torch.empty_like(x) if table.in_covered else _zeros_like(x))
+    dw = torch.empty_like(w) if (w is not None and want_w) else None
+    dM = torch.empty_like(coupling) if want_M else None
+    call("eqf_dtp_bwd", _p(x), _p(coupling), _p(w), table.c_ref, _p(dout), _p(dx), _p(dw), _p(dM), x.shape[0], _stream())
+    return dx, dM, dw
+
+
+class _DtpBwd(Function):
+    """(dx, dM, dw) of the un-fused depth-wise tensor product as a differentiable op of (x, M, w, dout).  The product
+    T(x, M, w) is trilinear, so with cotangents (cx, cM, cw) of the three outputs
+        Phi = <dout, T(cx, M, w)> + <dout, T(x, cM, w)> + <dout, T(x, M, cw)>
+    and every term of its gradient is T itself or one of its first-order backward maps with one argument swapped."""
+
+    @staticmethod
+    def forward(ctx, x, coupling, w, dout, table):
+        dout = _c(dout)
+        _chk(dout)
+        ctx.save_for_backward(x, coupling, w, dout)
+        ctx.table = table
+        dx, dM, dw = _dtp_bwd(x, coupling, w, dout, table)
+        return dx, dM, dw
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, cx, cM, cw):
+        x, M, w, dout = ctx.saved_tensors
+        t = ctx.table
+        g_x = g_M = g_w = g_d = None
+
+        def acc(a, b):
+            return b if a is None else (a if b is None else a + b)
+        if cx is not None:
+            cx = _c(cx)
+            _chk(cx)
+            g_d = acc(g_d, _dtp_fwd(cx, M, w, t))
+            _, m_, w_ = _dtp_bwd(cx, M, w, dout, t)
+            g_M, g_w = acc(g_M, m_), acc(g_w, w_)
+        if cM is not None:
+            cM = _c(cM)
+            _chk(cM)
+            g_d = acc(g_d, _dtp_fwd(x, cM, w, t))
+            x_, _, w_ = _dtp_bwd(x, cM, w, dout, t, want_M=False)
+            g_x, g_w = acc(g_x, x_), acc(g_w, w_)
+        if cw is not None and w is not None:
+            cw = _c(cw)
+            _chk(cw)
+            g_d = acc(g_d, _dtp_fwd(x, M, cw, t))
+            x_, m_, _ = _dtp_bwd(x, M, cw, dout, t, want_w=False)
+            g_x, g_M = acc(g_x, x_), acc(g_M, m_)
+        return g_x, g_M, g_w, g_d, None
 
 
 def dtp(x, coupling, w, table):
@@ -1390,6 +1447,8 @@ class DtpLinearSpec:
 
     def __init__(self, table, out_layout):
         self.table, self.out_layout = table, out_layout
+        if table.has_odd or out_layout.has_odd:
+            raise NotImplementedError("the DTP-generating GEMMs index their tables by degree: SE(3) irreps only")
         self.blocks = []  # (l3, K, N, w_off, mid_off, out_off)
         w_off = 0
         for (K, l3), mid_off in zip(table.layout_out.segs, table.layout_out.offsets):
@@ -1482,6 +1541,9 @@ class SfcSpec:
         self.table, self.out_layout, self.n2 = table, out_layout, int(n2)
         self.degs = []  # (l3, K, N1, Ncat)
         self.w_offs = []  # offset of the [K, N1] block of each degree in the flat main weight
+        if table.has_odd or out_layout.has_odd:  # E(3) irreps: the un-fused tensor product + linear serve them
+            self.supported = False
+            return
         ok = table.fusable
         for (N1, l3) in out_layout.segs:
             i = table.layout_out.seg_index(l3)

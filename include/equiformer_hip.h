@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define EQF_MAX_SEG 8
-#define EQF_MAX_PATHS 64
+#define EQF_MAX_PATHS 72
 
 #define EQF_E_BADARG (-1)
 #define EQF_E_UNSUPPORTED (-2)
@@ -41,6 +41,7 @@ typedef struct eqf_irreps {
   int nseg;
   int l[EQF_MAX_SEG];
   int mul[EQF_MAX_SEG];
+  int odd[EQF_MAX_SEG]; /* 1 = odd parity (E(3) models); 0 = even.  Only the 0e segments are "scalars" (mean, bias) */
 } eqf_irreps;
 
 /* Depth-wise tensor product ('uvu', mul2 == 1) path table.  Path p couples input segment of degree

@@ -1,0 +1,188 @@
+"""E(3) (parity-aware) model variants -- the `*_e3*` factories of the reference (nets/graph_attention_transformer.py:
+940-956, nets/graph_attention_transformer_md17.py:368-385, :465-482, :503-519, OC20 l1_256_e3 config): irreps such as
+'128x0e+32x0o+32x1e+32x1o+...' with spherical harmonics 1x0e+1x1o+1x2e.  Path tables, linears and the layer norm key
+on (degree, parity); the tensor products run un-fused.  HIP against the fp64 CPU oracle, 1e-4 relative."""
+import os
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets as onets
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from weights import fill_deterministic  # noqa: E402
+
+SMALL_E3_L2 = dict(irreps_node_embedding="32x0e+16x0o+16x1e+16x1o+8x2e+8x2o", num_layers=2, irreps_sh="1x0e+1x1o+1x2e",
+                   fc_neurons=[64, 64], irreps_feature="64x0e", irreps_head="8x0e+4x0o+4x1e+4x1o+4x2e+4x2o", num_heads=4,
+                   nonlinear_message=True, irreps_mlp_mid="64x0e+16x0o+32x1e+16x1o+16x2e+16x2o", alpha_drop=0.0)
+SMALL_E3_L3 = dict(irreps_node_embedding="32x0e+16x0o+16x1e+16x1o+8x2e+8x2o+8x3e+8x3o", num_layers=2,
+                   irreps_sh="1x0e+1x1o+1x2e+1x3o", fc_neurons=[64, 64], irreps_feature="64x0e",
+                   irreps_head="8x0e+4x0o+4x1e+4x1o+4x2e+4x2o+4x3e+4x3o", num_heads=4, nonlinear_message=True,
+                   irreps_mlp_mid="64x0e+16x0o+32x1e+16x1o+16x2e+16x2o+8x3e+8x3o", alpha_drop=0.0)
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _grad_check(ref, mod, loss_r, loss, tol):
+    gr = torch.autograd.grad(loss_r, list(ref.parameters()), allow_unused=True)
+    gg = torch.autograd.grad(loss, list(mod.parameters()), allow_unused=True)
+    scale = max(r.abs().max().item() for r in gr if r is not None)
+    worst, n_checked = ("", 0.0), 0
+    for (n, _), a, r in zip(ref.named_parameters(), gg, gr):
+        if r is None or r.abs().max() == 0:
+            continue
+        assert a is not None, n
+        e = (a.double().cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-3 * scale)
+        n_checked += 1
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < tol and n_checked > 50, (worst, n_checked)
+    return worst
+
+
+def test_layer_norm_and_gate_with_pseudo_scalars():
+    """0o channels are normalised without mean subtraction and carry no bias; in the gate they are gated, not activated."""
+    from equiformer_amd import ops, so3
+    from equiformer_amd.layout import RowLayout
+    from equiformer_amd.nets.layers import EquivariantLayerNormV2, make_gate
+    from oracle import nets as on
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    irreps = "16x0e+8x0o+8x1e+4x1o+4x2e"
+    lay = RowLayout(irreps)
+    x_e3 = torch.randn(19, lay.dim, generator=g, dtype=torch.float64) + 0.5
+    ln_r = on.EquivariantLayerNormV2(on.Irreps(irreps)).double()
+    ln = EquivariantLayerNormV2(irreps)
+    with torch.no_grad():
+        for p in ln_r.parameters():
+            p.copy_(torch.randn(p.shape, generator=g, dtype=torch.float64))
+    ln.load_state_dict({k: v.float() for k, v in ln_r.state_dict().items()})
+    ln = ln.to(dev)
+    assert ln.affine_bias.numel() == 16
+    xr = x_e3.clone().requires_grad_(True)
+    x = x_e3.float()[:, lay.perm_from_e3nn()].to(dev).requires_grad_(True)
+    yr, y = ln_r(xr), ln(x)
+    to_e3 = lay.perm_to_e3nn().to(dev)
+    assert _rel(y[:, to_e3], yr) < 1e-5
+    c = torch.randn(19, lay.dim, generator=g, dtype=torch.float64)
+    (gxr,) = torch.autograd.grad((yr * c).sum(), xr)
+    (gx,) = torch.autograd.grad((y * c.float()[:, lay.perm_from_e3nn()].to(dev)).sum(), x)
+    assert _rel(gx[:, to_e3], gxr) < 1e-5
+    # gate: scalars 16x0e are activated, everything else (0o included) is multiplied by sigmoid gates
+    gate_r = on.make_gate(on.Irreps(irreps))
+    gate = make_gate(irreps)
+    lin = RowLayout(gate.irreps_in)
+    z_e3 = torch.randn(19, lin.dim, generator=g, dtype=torch.float64)
+    zr = gate_r(z_e3)
+    z = gate(z_e3.float()[:, lin.perm_from_e3nn()].to(dev))
+    assert _rel(z[:, to_e3], zr) < 1e-5
+
+
+def test_e3_qm9_forward_backward_and_inversion():
+    from equiformer_amd.nets.graph_attention_transformer import GraphAttentionTransformer
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = _dev()
+    kw = dict(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **SMALL_E3_L2)
+    ref = fill_deterministic(onets.GraphAttentionTransformer(**kw), 51).double().eval()
+    mod = GraphAttentionTransformer(**kw)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
+    mod = mod.to(dev).eval()
+    assert not mod.blocks[0].ga.act_sfc_spec.supported and mod.blocks[0].ga.sep_act.dtp.table.has_odd
+    d = qm9_like_batch(6, 18, side=6.5, seed=2)
+    yr = ref(None, d["pos"].double(), d["batch"], d["z"])
+    y = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
+    assert _rel(y, yr) < 1e-4
+    y_inv = mod(None, (-d["pos"]).to(dev), d["batch"].to(dev), d["z"].to(dev))  # O(3): invariant under inversion
+    assert _rel(y_inv, y) < 1e-5
+    worst = _grad_check(ref, mod, (yr.squeeze() - d["y"].double()).abs().mean(),
+                        (y.squeeze() - d["y"].to(dev)).abs().mean(), 2e-4)
+    print("e3 qm9: energy rel %.2e, inversion %.1e, worst parameter gradient %s %.2e"
+          % (_rel(y, yr), _rel(y_inv, y), *worst))
+
+
+@pytest.mark.parametrize("cfg", ["SMALL_E3_L2", "SMALL_E3_L3"])
+def test_e3_md17_forces_and_second_order(cfg):
+    from equiformer_amd.nets.graph_attention_transformer_md17 import GraphAttentionTransformerMD17
+    from equiformer_amd.synthetic import md17_aspirin_batch
+    dev = _dev()
+    kw = dict(irreps_in="64x0e", max_radius=5.0, number_of_basis=32, basis_type="exp", **globals()[cfg])
+    ref = fill_deterministic(onets.GraphAttentionTransformerMD17(**kw), 52).double().train()
+    mod = fill_deterministic(GraphAttentionTransformerMD17(**kw), 52).to(dev).train()
+    d = md17_aspirin_batch(2, seed=3)
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(2, 1, generator=g, dtype=torch.float64)
+    B = torch.randn(42, 3, generator=g, dtype=torch.float64)
+    Er, Fr = ref(d["z"], d["pos"].double(), d["batch"])
+    E, F = mod(d["z"].to(dev), d["pos"].to(dev), d["batch"].to(dev))
+    assert F.requires_grad and _rel(E, Er) < 1e-4 and _rel(F, Fr) < 1e-4
+    worst = _grad_check(ref, mod, (a * Er).sum() + (B * Fr).sum(),
+                        (a.float().to(dev) * E).sum() + (B.float().to(dev) * F).sum(), 2e-4)
+    print("e3 md17 %s: E rel %.2e, F rel %.2e, worst second-order gradient %s %.2e" % (cfg, _rel(E, Er), _rel(F, Fr), *worst))
+
+
+def test_e3_registered_models_full_width():
+    """graph_attention_transformer_nonlinear_l2_e3 (QM9) and ..._exp_l3_e3_md17 (68 tensor-product paths) as registered,
+    random init shared with the oracle; OC20 l1_256_e3 on a periodic slab."""
+    from equiformer_amd import nets
+    from equiformer_amd.synthetic import md17_aspirin_batch, qm9_like_batch
+    from test_gpu_oc20_heads import _slab
+    dev = _dev()
+    torch.manual_seed(0)
+    e3l2 = dict(irreps_node_embedding="128x0e+32x0o+32x1e+32x1o+16x2e+16x2o", irreps_sh="1x0e+1x1o+1x2e",
+                irreps_head="32x0e+8x0o+8x1e+8x1o+4x2e+4x2o", irreps_mlp_mid="384x0e+96x0o+96x1e+96x1o+48x2e+48x2o")
+    ref = onets.GraphAttentionTransformer(irreps_in="5x0e", num_layers=6, max_radius=5.0, number_of_basis=128,
+                                          fc_neurons=[64, 64], irreps_feature="512x0e", num_heads=4,
+                                          nonlinear_message=True, alpha_drop=0.2, **e3l2).double().eval()
+    mod = nets.model_entrypoint("graph_attention_transformer_nonlinear_l2_e3")("5x0e", 5.0)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
+    mod = mod.to(dev).eval()
+    d = qm9_like_batch(4, 18, side=6.5, seed=0)
+    with torch.no_grad():
+        yr = ref(None, d["pos"].double(), d["batch"], d["z"])
+        y = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
+    print("l2_e3 full width: energy rel %.3e" % _rel(y, yr))
+    assert _rel(y, yr) < 1e-4
+
+    e3l3 = dict(irreps_node_embedding="128x0e+64x0o+32x1e+32x1o+32x2e+32x2o+16x3e+16x3o", irreps_sh="1x0e+1x1o+1x2e+1x3o",
+                irreps_head="32x0e+16x0o+8x1e+8x1o+8x2e+8x2o+4x3e+4x3o",
+                irreps_mlp_mid="384x0e+192x0o+96x1e+96x1o+96x2e+96x2o+48x3e+48x3o")
+    ref = onets.GraphAttentionTransformerMD17(irreps_in="64x0e", num_layers=2, max_radius=5.0, number_of_basis=32,
+                                              basis_type="exp", fc_neurons=[64, 64], irreps_feature="512x0e", num_heads=4,
+                                              nonlinear_message=True, alpha_drop=0.0, **e3l3).double().eval()
+    from equiformer_amd.nets.graph_attention_transformer_md17 import _E3_L3, _md17
+    mod = _md17("64x0e", 5.0, 32, None, None, None, num_layers=2, **_E3_L3)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
+    mod = mod.to(dev).eval()
+    assert len(mod.blocks[0].ga.sep_act.dtp.table.paths) == 68
+    m = md17_aspirin_batch(1, seed=1)
+    Er, Fr = ref(m["z"], m["pos"].double(), m["batch"])
+    E, F = mod(m["z"].to(dev), m["pos"].to(dev), m["batch"].to(dev))
+    print("l3_e3 md17 (2 blocks, full width): E rel %.3e F rel %.3e" % (_rel(E, Er), _rel(F, Fr)))
+    assert _rel(E, Er) < 1e-4 and _rel(F, Fr) < 1e-4
+
+    over = dict(num_layers=2, irreps_node_embedding="256x0e+64x0o+64x1e+64x1o", irreps_sh="1x0e+1x1o",
+                irreps_head="32x0e+8x0o+8x1e+8x1o", irreps_pre_attn="256x0e+64x0o+64x1e+64x1o",
+                irreps_mlp_mid="768x0e+192x0o+192x1e+192x1o")
+    ref = onets.oc20_l1_256_nonlinear(**over).double().eval()
+    mod = nets.model_entrypoint("oc20_l1_256_e3_nonlinear")(num_layers=2)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
+    mod = mod.to(dev).eval()
+    pos, batch, Z, tags, ei, off = _slab(2, 24, seed=7)
+    with torch.no_grad():
+        er = ref(Z, tags, pos.double(), batch, edge_index=ei, offsets=off.double())
+        e = mod(SimpleNamespace(pos=pos.to(dev), batch=batch.to(dev), atomic_numbers=Z.to(dev), tags=tags.to(dev),
+                                edge_index=ei.to(dev), offsets=off.to(dev)))
+    print("oc20 l1_256_e3 (2 blocks): energy rel %.3e" % _rel(e, er))
+    assert _rel(e, er) < 1e-4

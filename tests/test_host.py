@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_struct_layouts_match_header():
     from equiformer_amd import lib
-    assert ctypes.sizeof(lib.EqfIrreps) == 4 * (1 + 2 * lib.EQF_MAX_SEG)
+    assert ctypes.sizeof(lib.EqfIrreps) == 4 * (1 + 3 * lib.EQF_MAX_SEG)  # nseg, l[], mul[], odd[]
     assert ctypes.sizeof(lib.EqfDtpPaths) == 4 * (6 + 11 * lib.EQF_MAX_PATHS)
     assert ctypes.sizeof(lib.EqfRows) == 12
 
@@ -67,8 +67,16 @@ def test_registry_and_factories():
     for name in ("graph_attention_transformer_l2_md17", "graph_attention_transformer_nonlinear_bessel_l2_md17",
                  "graph_attention_transformer_nonlinear_bessel_l3_md17", "graph_attention_transformer_nonlinear_l2_md17"):
         assert callable(nets.model_entrypoint(name))
-    with pytest.raises(NotImplementedError):  # E(3) (parity-aware) irreps are not on the hot path
-        nets.model_entrypoint("graph_attention_transformer_nonlinear_l2_e3")("5x0e", 5.0)
+    # E(3) (parity-aware) irreps: built, on the un-fused tensor-product kernels (the fused ones key on the degree only)
+    me = nets.model_entrypoint("graph_attention_transformer_nonlinear_l2_e3")("5x0e", 5.0)
+    assert sum(p.numel() for p in me.parameters()) == 3282211
+    t = me.blocks[0].ga.sep_act.dtp.table
+    assert t.has_odd and not t.fusable and len(t.paths) == 30 and not me.blocks[0].ga.act_sfc_spec.supported
+    assert repr(t.irreps_out) == "176x0e+80x0o+160x1e+256x1o+240x2e+144x2o"
+    assert me.blocks[0].norm_1.affine_bias.numel() == 128  # bias on 0e only
+    for name in ("graph_attention_transformer_nonlinear_l2_e3_md17", "graph_attention_transformer_nonlinear_exp_l3_e3_md17",
+                 "graph_attention_transformer_nonlinear_bessel_l3_e3_md17", "oc20_l1_256_e3_nonlinear"):
+        assert callable(nets.model_entrypoint(name))
 
 
 def test_oc20_and_md17_head_variants_build_with_reference_keys():
@@ -191,8 +199,10 @@ def test_layout_permutations_roundtrip():
     assert torch.equal(cf[:, lay.perm_to_e3nn()], x)
     # e3nn element (seg 1, u=2, m=1) sits at 8 + 2*3 + 1; in CF at 8 + 1*4 + 2
     assert cf[0, 8 + 1 * 4 + 2].item() == 8 + 2 * 3 + 1
+    e3 = RowLayout("8x0e+2x0o+4x1e+4x1o")  # E(3) rows: one segment per (degree, parity), even first
+    assert e3.par == [1, -1, 1, -1] and e3.seg_index(1, -1) == 3 and e3.mul_of(0, -1) == 2 and e3.c.odd[1] == 1
     with pytest.raises(NotImplementedError):
-        RowLayout("8x0e+4x1o")
+        RowLayout("8x0e+4x1o+4x1e")  # odd before even: not the sorted order every reference model uses
 
 
 def test_dtp_table_matches_oracle_instructions():
