@@ -83,6 +83,52 @@ def oc20(B=16, Na=78):
           % ("oc20_l1_256_nonlinear (otf_graph, use_pbc)", B, Na, gr.E, tt, B / tt * 1e3), flush=True)
 
 
+def qm9(name, B=128):
+    """QM9-shaped train step (the bench.py workload) of another registered model family."""
+    from equiformer_amd.synthetic import qm9_like_batch
+    torch.manual_seed(0)
+    model = nets.model_entrypoint(name)(irreps_in="5x0e", radius=5.0, num_basis=128).to(dev).train()
+    opt = FlatAdamW(add_weight_decay(model, 5e-3, model.no_weight_decay()), lr=5e-4)
+    d = {k: v.to(dev) for k, v in qm9_like_batch(B, 18, side=6.5, seed=0).items()}
+
+    def train():
+        opt.zero_grad(set_to_none=True)
+        y = model(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"])
+        (y.squeeze() - d["y"]).abs().mean().backward()
+        opt.step()
+
+    tt = timed(train, n=8, warm=3)
+    print("%-55s %d molecules: train step %.2f ms (%.0f molecules/s)" % (name, B, tt, B / tt * 1e3), flush=True)
+
+
+def dens(frames=5):
+    torch.manual_seed(0)
+    model = nets.model_entrypoint("equiformer_md17_dens_l2")().to(dev).train()
+    opt = FlatAdamW(add_weight_decay(model, 1e-6, model.no_weight_decay()), lr=2e-4)
+    d = {k: v.to(dev) for k, v in md17_aspirin_batch(frames, seed=1).items()}
+    n = frames * 21
+    data = SimpleNamespace(z=d["z"], pos=d["pos"], batch=d["batch"], force=torch.randn(n, 3, device=dev),
+                           noise_mask=torch.rand(n, device=dev) < 0.25)
+    ty, tf = torch.randn(frames, 1, device=dev), torch.randn(n, 3, device=dev)
+
+    def train():
+        opt.zero_grad(set_to_none=True)
+        E, Y = model(data)
+        ((E - ty).abs().mean() + 80.0 * (Y - tf).norm(dim=1).mean()).backward()
+        opt.step()
+
+    tt = timed(train, n=8, warm=3)
+    print("%-55s frames %d (25 %% corrupted atoms): train step %.2f ms (%.0f frames/s)"
+          % ("equiformer_md17_dens_l2", frames, tt, frames / tt * 1e3), flush=True)
+
+
 md17("graph_attention_transformer_nonlinear_exp_l2_md17", 8, 80.0)
 md17("graph_attention_transformer_nonlinear_exp_l3_md17", 5, 100.0)
 oc20()
+if "--variants" in sys.argv:
+    for name in ("graph_attention_transformer_l2", "graph_attention_transformer_nonlinear_bessel_l2",
+                 "dot_product_attention_transformer_l2", "graph_attention_transformer_nonlinear_l2_e3"):
+        qm9(name)
+    md17("dot_product_attention_transformer_exp_l2_md17", 8, 80.0)
+    md17("graph_attention_transformer_nonlinear_attn_exp_l3_md17", 5, 100.0)
+    dens()
