@@ -14,7 +14,7 @@ from equiformer_amd.layout import DtpTable, RowLayout  # noqa: E402
 from equiformer_amd.lib import call  # noqa: E402
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 25354
-STATS = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+STATS = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 0
 MASKS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 0, 128, 256, 512, 1024, 32]
 dev = torch.device("cuda:0")
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -47,14 +47,49 @@ def run(name, irr, sh_irr, out_irr, n2, use_w):
     ref = fwd(64 ^ X6_BIT)  # exact-fp32 MFMA step
     scale = ref.abs().max().item()
     if STATS:
+        dbg = torch.zeros(8, dtype=torch.int64, device=dev)
         for mask in MASKS:
             nbad = nrows = 0
+            dbg.zero_()
+            if mask & (262144 | 524288 | 1048576 | 4194304):
+                L.eqf_sfc_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
             for rep in range(STATS):
                 a = fwd(mask ^ X6_BIT)  # masks are relative to the split-precision step
                 bad = (a - ref).abs() > 1e-5 * scale
+                if bad.any() and nbad < 3 and "--match" in sys.argv:
+                    # is a bad output row some OTHER row's correct result (or a mix)?  compare with every row of its tile
+                    rows = bad.any(1).nonzero().flatten()
+                    for rr in rows[:6].tolist():
+                        t0 = (rr // 64) * 64
+                        cols = bad[rr].nonzero().flatten()
+                        blk = ref[t0:t0 + 64][:, cols]
+                        d = (blk - a[rr, cols][None]).abs().max(1).values / scale
+                        best = int(d.argmin())
+                        per_tile = [(int(c0), "%.1e" % ((a[rr, c0:c0 + 32] - ref[rr, c0:c0 + 32]).abs().max() / scale).item())
+                                    for c0 in range(int(cols[0]) // 32 * 32, int(cols[-1]) + 1, 32)]
+                        print("   row %d (in-tile %d): closest reference row of the tile = in-tile %d (max diff %.1e of scale); "
+                              "a/ref first bad cols %s / %s; per 32-col tile max err %s"
+                              % (rr, rr % 64, best, d[best].item(), [round(v, 3) for v in a[rr, cols[:4]].tolist()],
+                                 [round(v, 3) for v in ref[rr, cols[:4]].tolist()], per_tile), flush=True)
+                if bad.any() and nbad < 4:  # pattern of the first few failures
+                    rows = bad.any(1).nonzero().flatten()
+                    for rr in rows[:4].tolist():
+                        cols = bad[rr].nonzero().flatten()
+                        rel = ((a[rr] - ref[rr]).abs().max() / scale).item()
+                        print("   bad row %d (tile %d, row-in-tile %d): %d bad columns %s..%s, max err %.2e of scale"
+                              % (rr, rr // 64, rr % 64, cols.numel(), cols[:3].tolist(), cols[-3:].tolist(), rel), flush=True)
                 nbad += int(bad.any())
                 nrows += int(bad.any(1).sum())
-            print("%s mask %5d: %d of %d runs wrong, %d bad rows in total" % (name, mask, nbad, STATS, nrows), flush=True)
+            L.eqf_sfc_debug_buffer(None)
+            print("%s mask %5d: %d of %d runs wrong, %d bad rows in total%s" % (name, mask, nbad, STATS, nrows,
+                  ("; readback mismatches after the write barrier %d, at the end of the MFMA phase %d"
+                   % (dbg[6].item(), dbg[7].item())) if mask & 262144 else "")
+                  + (("; prefetched x registers differing from a fresh load %d, w registers %d" % (dbg[4].item(), dbg[5].item()))
+                     if mask & 524288 else "")
+                  + (("; generation expressions that differ when evaluated twice %d" % dbg[3].item()) if mask & 1048576 else "")
+                  + (("; same registers, arithmetic twice: %d differ; same address, LDS read twice: %d differ"
+                      % (dbg[2].item(), dbg[1].item())) if mask & 4194304 else ""),
+                  flush=True)
         return
     for rep, mask in enumerate(MASKS):
         a = fwd(mask ^ X6_BIT)
