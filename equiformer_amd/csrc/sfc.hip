@@ -37,11 +37,18 @@ unsigned long long* g_sfc_dbg = nullptr;  // set by eqf_sfc_debug_buffer (develo
 // 8-12 % faster for bwd_weight, 0-6 % for bwd_data, and 0-14 % SLOWER for fwd (its workgroups of one degree share the
 // staged weight slabs, which the degree-major order keeps hot).  eqf_sfc_debug_order overrides all three for A/B runs.
 int g_sfc_order[3] = {0, 1, 1};
-// forward matrix step: exact-fp32 MFMA (false) or split-precision bf16 x 6 (true).  The split-precision step is OFF:
-// at the bench size (E = 25 k edges) it returns run-to-run different results in ~1 % of the launches (one VGPR of the
-// generation phase clobbered in lanes 48..63 -> two rows of an edge tile wrong by ~10 %; tools/sfc_race.py,
-// gpurun_out/r2a, r2b).  It passed every test at E <= 333, which is how it shipped in round 1.  Not root-caused; kept
-// behind eqf_sfc_debug_exp(64) for that investigation only.
+// forward matrix step: exact-fp32 MFMA (false, the default) or split-precision bf16 x 6 on the matrix cores (true; f_mma6).
+// History: the split-precision step shipped in round 1, was found to return run-to-run different results at the bench size
+// (E = 25 k edges: two rows of an edge tile wrong by ~1e-2 in a few launches out of a hundred) and was switched off.
+// Root cause (round 2, profiles/r02/x6_investigation/): not the matrix step itself -- the PACKED-FP32 VALU instructions
+// (v_pk_fma_f32 / v_pk_mul_f32) hipcc emitted for the generation of the A tile return wrong values in lanes 48-63 now
+// and then while the co-resident workgroup's wave on the same SIMD runs the bf16 MFMAs.  The kernel variant that issues
+// bf16 MFMAs therefore contains no packed-FP32 instruction any more (x6_fmac / x6_mul / x6_sub): 0 wrong results in
+// 2 400 launches, full-size parity tests green with it.  Scalar instead of packed VALU work costs most of what the matrix
+// cores gained (interleaved A/B, tools/sfc_fwd_ab.py: sep_act 211.4 us vs 219.8 us with the fp32 step, sep_value 158.6 vs
+// 166.2; it was 203 vs 228 with the packed instructions): 0.6 % of a train step.  Not enough to change the default at
+// the end of a round whose first job was determinism: the exact-fp32 step stays the default, eqf_sfc_debug_exp(64)
+// selects the split-precision one (tests/test_gpu_fullsize.py keeps it bit-reproducible).
 bool g_sfc_x6_default = false;
 int g_sfc_exp = 0;  // development aid (eqf_sfc_debug_exp): bit mask that switches phases of the kernels OFF to time the rest
 
@@ -191,34 +198,35 @@ __device__ __forceinline__ void f_mma(const int (&aidx)[FT], const int (&bidx)[F
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int X6_SA = 36;  // floats per A row: 32 k + 4 pad (16-byte aligned rows, staggered banks)
 
+// Plain (non-packed) VALU instruction, whatever the optimiser would like to do with neighbouring lanes of a vector:
+// packed-FP32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) must not run in a kernel that also issues the
+// bf16 MFMAs -- see X6_NOTE below.
+__device__ __forceinline__ float x6_sub(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void x6_fmac(float& acc, float a, float b) { asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+__device__ __forceinline__ float x6_mul(float a, float b) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const __bf16 h = (__bf16)v[j];
-    const float r1 = v[j] - (float)h;
+    const float r1 = x6_sub(v[j], (float)h);
     const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
+    const float r2 = x6_sub(r1, (float)m);
     p1[j] = h, p2[j] = m, p3[j] = (__bf16)r2;
   }
 }
 
 template <int D3, int NT, int FT>
-__device__ __forceinline__ void f_mma6(const int (&arow)[FT], const int (&bcol)[FT], f32x16 (&acc)[FT],
-                                       const int spacing) {
+__device__ __forceinline__ void f_mma6(const int (&arow)[FT], const int (&bcol)[FT], f32x16 (&acc)[FT]) {
   constexpr int F_SB = f_sb(D3, FT);
-  if (spacing & 65536) {  // experiment: exact-fp32 MFMA reading the SAME row-major A tile (isolates layout from arithmetic)
-    const int hi = ((int)threadIdx.x & 63) >> 5;
-#pragma unroll 4
-    for (int kk = 0; kk < 16; ++kk) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const float av = sfc_lds[arow[i] - 8 * hi + 2 * kk + hi];
-        const float bw = sfc_lds[bcol[i] - 8 * hi * F_SB + (2 * kk + hi) * F_SB];
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw, acc[i], 0, 0, 0);
-      }
-    }
-    return;
-  }
 #pragma unroll
   for (int kg = 0; kg < 2; ++kg) {  // two groups of 16 k per 32-channel slab
     bf16x8 x1, x2, x3, y1, y2, y3;
@@ -226,19 +234,10 @@ __device__ __forceinline__ void f_mma6(const int (&arow)[FT], const int (&bcol)[
     for (int i = 0; i < NT; ++i) {
       {
         float av[8];
-        if (spacing & 2097152) {  // experiment: 64-bit LDS reads (volatile: not merged back) instead of 128-bit ones
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg]);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg + 4]);
 #pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            const f32x2 v = *reinterpret_cast<const volatile f32x2*>(&sfc_lds[arow[i] + 16 * kg + 2 * h]);
-            av[2 * h] = v[0], av[2 * h + 1] = v[1];
-          }
-        } else {
-          const f32x4 a0 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg]);
-          const f32x4 a1 = *reinterpret_cast<const f32x4*>(&sfc_lds[arow[i] + 16 * kg + 4]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) av[j] = a0[j], av[4 + j] = a1[j];
-        }
+        for (int j = 0; j < 4; ++j) av[j] = a0[j], av[4 + j] = a1[j];
         split3(av, x1, x2, x3);
       }
       {
@@ -247,22 +246,12 @@ __device__ __forceinline__ void f_mma6(const int (&arow)[FT], const int (&bcol)[
         for (int j = 0; j < 8; ++j) bw[j] = sfc_lds[bcol[i] + (16 * kg + j) * F_SB];
         split3(bw, y1, y2, y3);
       }
-      // `spacing` (development switch 2048): wait states between the dependent accumulations, to tell an
-      // accumulator-forwarding hazard of the back-to-back bf16 MFMAs from a memory race
-#define X6_GAP() do { if (spacing & 2048) { asm volatile("s_nop 15\n\ts_nop 15"); } } while (0)
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, y2, acc[i], 0, 0, 0);
-      X6_GAP();
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, y3, acc[i], 0, 0, 0);
-      X6_GAP();
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, y1, acc[i], 0, 0, 0);
-      X6_GAP();
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, y2, acc[i], 0, 0, 0);
-      X6_GAP();
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, y1, acc[i], 0, 0, 0);
-      X6_GAP();
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, y1, acc[i], 0, 0, 0);
-      X6_GAP();
-#undef X6_GAP
     }
   }
 }
@@ -340,7 +329,6 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
   f32x4 xv[2][MAXD], wv[2];
   f32x4 bv[CTCAP];
   int s_d1 = 0, s_mo = 0;  // of the slab whose inputs are in xv / wv / bv
-  int s_xo = 0, s_wo = 0;  // (reload experiment, development switch 524288)
   auto load_x = [&](auto tag, const SfcSlab& S) __attribute__((always_inline)) {
     constexpr int D1 = decltype(tag)::value;
     const float* xs = g.c.x + S.x_off + 4 * c4;
@@ -355,7 +343,6 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     const SfcSlab S = g.c.slab[D.slab0 + s];
     s_d1 = S.d1;
     s_mo = S.m_off - D.m_base;
-    s_xo = S.x_off, s_wo = S.w_off;
     if (g.c.w) {
       const float* ws = g.c.w + S.w_off + 4 * c4;
 #pragma unroll
@@ -383,92 +370,43 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
   };
   const int awb = AS0 + (4 * c4) * SA + eg;
   const int mrow = MT0 + eg * m_len;
-  f32x4 chk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  auto readback = [&](int slot) __attribute__((always_inline)) {
-    if (X6 && (g.exp & 262144) && g.dbg) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&sfc_lds[AS0 + (eg + 32 * q) * X6_SA + 4 * c4]);
-        const bool same = __float_as_uint(v[0]) == __float_as_uint(chk[q][0]) && __float_as_uint(v[1]) == __float_as_uint(chk[q][1]) &&
-                          __float_as_uint(v[2]) == __float_as_uint(chk[q][2]) && __float_as_uint(v[3]) == __float_as_uint(chk[q][3]);
-        if (!same) atomicAdd(g.dbg + slot, 1ull);
-      }
-    }
-  };
   auto gen = [&](auto tag) __attribute__((always_inline)) {
     constexpr int D1 = decltype(tag)::value;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int mp = mrow + (32 * q) * m_len + s_mo;
-      const f32x4 wm = wv[q] * emask[q];
+      f32x4 wm;
+      if (X6) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wm[c] = x6_mul(wv[q][c], emask[q]);
+      } else {
+        wm = wv[q] * emask[q];
+      }
 #pragma unroll
       for (int m3 = 0; m3 < D3; ++m3) {
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < D1; ++i) a += xv[q][i] * sfc_lds[mp + i * D3 + m3];
-        a *= wm;
-        if (X6 && (g.exp & 8388608)) {  // experiment: the same value with scalar (non-packed) VALU instructions only
+        if (X6) {
+          // X6_NOTE: scalar VALU instructions only.  With the vector expression below hipcc emits v_pk_fma_f32 /
+          // v_pk_mul_f32, and on MI355X a packed-FP32 instruction of this wave returns a wrong result in lanes 48-63
+          // every now and then while the OTHER wave of its SIMD (the co-resident workgroup) runs the bf16 MFMA step:
+          // measured with the same registers fed twice to the same expression (tools/sfc_race.py, profiles/r02/
+          // x6_investigation/: 8 differing evaluations per wrong output row, none with one workgroup per CU, none with
+          // the fp32 MFMA, none with these scalar instructions; LDS contents and prefetched registers verified intact).
           float ac[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int i = 0; i < D1; ++i) {
             const float m = sfc_lds[mp + i * D3 + m3];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float xc = xv[q][i][c];
-              asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(ac[c]) : "v"(xc), "v"(m));
-            }
+            for (int c = 0; c < 4; ++c) x6_fmac(ac[c], xv[q][i][c], m);
           }
+          f32x4 a;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float wc = wm[c];
-            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(ac[c]) : "v"(wc));
-          }
-          a = f32x4{ac[0], ac[1], ac[2], ac[3]};
-        }
-        if (X6 && (g.exp & 4194304) && g.dbg) {  // experiment: ONE set of LDS reads, the arithmetic done twice
-          float mv[D1];
-#pragma unroll
-          for (int i = 0; i < D1; ++i) mv[i] = sfc_lds[mp + i * D3 + m3];
-          f32x4 b1 = f32x4{0.f, 0.f, 0.f, 0.f}, b2 = b1;
-#pragma unroll
-          for (int i = 0; i < D1; ++i) b1 += xv[q][i] * mv[i];
-#pragma unroll
-          for (int i = 0; i < D1; ++i) asm volatile("" : "+v"(mv[i]));
-#pragma unroll
-          for (int i = 0; i < D1; ++i) b2 += xv[q][i] * mv[i];
-          const bool same = __float_as_uint(b1[0]) == __float_as_uint(b2[0]) && __float_as_uint(b1[1]) == __float_as_uint(b2[1]) &&
-                            __float_as_uint(b1[2]) == __float_as_uint(b2[2]) && __float_as_uint(b1[3]) == __float_as_uint(b2[3]);
-          if (!same) atomicAdd(g.dbg + 2, 1ull);
-          // ... and ONE arithmetic, the LDS value read twice
-          bool msame = true;
-#pragma unroll
-          for (int i = 0; i < D1; ++i)
-            msame = msame && __float_as_uint(mv[i]) == __float_as_uint(*reinterpret_cast<volatile float*>(&sfc_lds[mp + i * D3 + m3]));
-          if (!msame) atomicAdd(g.dbg + 1, 1ull);
-        }
-        if (X6 && (g.exp & 1048576) && g.dbg) {  // experiment: the same expression evaluated twice by the same thread
-          asm volatile("" ::: "memory");
-          f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int i = 0; i < D1; ++i) a2 += xv[q][i] * *reinterpret_cast<volatile float*>(&sfc_lds[mp + i * D3 + m3]);
-          a2 *= wm;
-          const bool same = __float_as_uint(a2[0]) == __float_as_uint(a[0]) && __float_as_uint(a2[1]) == __float_as_uint(a[1]) &&
-                            __float_as_uint(a2[2]) == __float_as_uint(a[2]) && __float_as_uint(a2[3]) == __float_as_uint(a[3]);
-          if (!same) atomicAdd(g.dbg + 3, 1ull);
-        }
-        if (X6) {
-          float* dstp = &sfc_lds[AS0 + (m3 * F_TE + eg + 32 * q) * X6_SA + 4 * c4];
-          if (m3 == 0) chk[q] = a;  // readback experiment (development switch 262144)
-          if (g.exp & 4096) {  // experiment: wait states between the VALU that produces `a` and the 128-bit LDS store
-            asm volatile("s_nop 7" ::: "memory");
-            *reinterpret_cast<f32x4*>(dstp) = a;
-          } else if (g.exp & 8192) {  // experiment: 128-bit store, LDS queue drained before `a` is overwritten
-            *reinterpret_cast<f32x4*>(dstp) = a;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          } else {
-            *reinterpret_cast<f32x4*>(dstp) = a;
-          }
+          for (int c = 0; c < 4; ++c) a[c] = x6_mul(ac[c], wm[c]);
+          *reinterpret_cast<f32x4*>(&sfc_lds[AS0 + (m3 * F_TE + eg + 32 * q) * X6_SA + 4 * c4]) = a;
         } else {
+          f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < D1; ++i) a += xv[q][i] * sfc_lds[mp + i * D3 + m3];
+          a *= wm;
 #pragma unroll
           for (int c = 0; c < 4; ++c) sfc_lds[awb + c * SA + 32 * q + m3 * F_TE] = a[c];
         }
@@ -477,21 +415,6 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
   };
   const int bwp = BS0 + (t >> 3) * F_SB + 4 * (t & 7);
   auto commit = [&]() __attribute__((always_inline)) {
-    if ((g.exp & 524288) && g.dbg) {  // experiment: do the prefetched registers hold what memory holds?
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f32x4 x2 = *reinterpret_cast<const f32x4*>(g.c.x + s_xo + 4 * c4 + erow[q] * x_ld);
-        const bool sx = __float_as_uint(x2[0]) == __float_as_uint(xv[q][0][0]) && __float_as_uint(x2[1]) == __float_as_uint(xv[q][0][1]) &&
-                        __float_as_uint(x2[2]) == __float_as_uint(xv[q][0][2]) && __float_as_uint(x2[3]) == __float_as_uint(xv[q][0][3]);
-        if (!sx) atomicAdd(g.dbg + 4, 1ull);
-        if (g.c.w) {
-          const f32x4 w2 = *reinterpret_cast<const f32x4*>(g.c.w + s_wo + 4 * c4 + erow[q] * w_ld);
-          const bool sw = __float_as_uint(w2[0]) == __float_as_uint(wv[q][0]) && __float_as_uint(w2[1]) == __float_as_uint(wv[q][1]) &&
-                          __float_as_uint(w2[2]) == __float_as_uint(wv[q][2]) && __float_as_uint(w2[3]) == __float_as_uint(wv[q][3]);
-          if (!sw) atomicAdd(g.dbg + 5, 1ull);
-        }
-      }
-    }
     if (!(g.exp & 2)) switch (s_d1) {
       case 1: gen(IC<1>()); break;
       case 3: gen(IC<3>()); break;
@@ -504,7 +427,7 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
 
   unsigned long long t_mark = g.dbg ? __builtin_amdgcn_s_memtime() : 0;
   auto tick = [&](int slot) __attribute__((always_inline)) {
-    if (g.dbg && !(g.exp & (262144 | 524288 | 1048576 | 4194304))) {  // (the check experiments count events in the same buffer)
+    if (g.dbg) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
       if (t == 0) atomicAdd(g.dbg + slot, now - t_mark);
       t_mark = now;
@@ -542,18 +465,16 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     tick(1);  // wait for the prefetched inputs + generation + LDS writes
     __syncthreads();
     tick(2);  // barrier
-    readback(6);  // what every thread wrote is what the tile holds once all writes are done?
-    if (s + 1 < nslab && !(g.exp & 4) && !(g.exp & 16384)) issue(s + 1);
-    if (g.exp & 32768) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment: loads land before the MFMAs start
+    if (s + 1 < nslab && !(g.exp & 4)) issue(s + 1);
     tick(3);  // issue of the next slab's loads
     if (!(g.exp & 1)) {
       if constexpr (X6) {
         switch (NT) {
-          case 1: f_mma6<D3, 1, FT>(aidx, bidx, acc, g.exp & (2048 | 65536 | 2097152)); break;
-          case 2: f_mma6<D3, 2, FT>(aidx, bidx, acc, g.exp & (2048 | 65536 | 2097152)); break;
-          case 3: f_mma6<D3, 3, FT>(aidx, bidx, acc, g.exp & (2048 | 65536 | 2097152)); break;
+          case 1: f_mma6<D3, 1, FT>(aidx, bidx, acc); break;
+          case 2: f_mma6<D3, 2, FT>(aidx, bidx, acc); break;
+          case 3: f_mma6<D3, 3, FT>(aidx, bidx, acc); break;
           default:
-            if constexpr (FT >= 4) f_mma6<D3, 4, FT>(aidx, bidx, acc, g.exp & (2048 | 65536 | 2097152));
+            if constexpr (FT >= 4) f_mma6<D3, 4, FT>(aidx, bidx, acc);
             break;
         }
       } else {
@@ -568,12 +489,6 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
       }
     }
     tick(4);  // MFMA loop
-    if (s + 1 < nslab && (g.exp & 16384)) issue(s + 1);  // experiment: no loads in flight during the MFMA phase
-    readback(7);  // ... and still at the end of the MFMA phase?
-    if (g.exp & 131072) {  // experiment: let the queued bf16 MFMAs drain before anything else is issued
-#pragma unroll
-      for (int d = 0; d < 40; ++d) asm volatile("s_nop 15");
-    }
     __syncthreads();
     tick(5);  // barrier
   }

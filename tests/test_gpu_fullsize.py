@@ -96,6 +96,38 @@ def test_sfc_bench_size_is_deterministic(irr, sh_irr, out_irr, n2, use_w):
                     assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("irr,sh_irr,out_irr,n2,use_w", SHAPES)
+def test_sfc_split_precision_step_is_deterministic_and_accurate(irr, sh_irr, out_irr, n2, use_w):
+    """The forward's OTHER matrix step (bf16 matrix cores on 3-way split fp32 operands, development switch 64 of
+    include/equiformer_hip_dev.h).  It was the source of round 1's run-to-run differences at this size: packed-FP32 VALU
+    instructions beside the bf16 MFMAs of a co-resident wave.  Kept honest here: 60 launches bit-equal,
+    and within 1e-5 of the exact-fp32 step."""
+    from equiformer_amd import lib, ops
+    dev = _dev()
+    table, lay_out, spec, x, sh, w, weight, weight2, bias, bias2, g = _sfc_inputs(irr, sh_irr, out_irr, n2, use_w,
+                                                                                 E_BENCH, dev)
+    L = lib.load()
+    with torch.no_grad():
+        M = ops.dtp_coupling(sh, table)
+        ref = [t.clone() for t in ops._sfc_fwd(x, M, w, weight, bias, weight2, bias2, spec) if t is not None]
+        try:
+            L.eqf_sfc_debug_exp(64)
+            first = None
+            for rep in range(60):
+                cur = [t for t in ops._sfc_fwd(x, M, w, weight, bias, weight2, bias2, spec) if t is not None]
+                torch.cuda.synchronize()
+                if first is None:
+                    first = [t.clone() for t in cur]
+                    for a, b in zip(first, ref):
+                        assert _rel(a, b) < 1e-5
+                    assert any(not torch.equal(a, b) for a, b in zip(first, ref)), "the switch selected no other step"
+                else:
+                    for k, (a, b) in enumerate(zip(cur, first)):
+                        assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
+        finally:
+            L.eqf_sfc_debug_exp(0)
+
+
 def _bench_batch():
     from equiformer_amd.synthetic import qm9_like_batch
     return qm9_like_batch(128, 18, side=6.5, seed=11)
