@@ -128,6 +128,13 @@ class _Trunk(nn.Module):
     use_radial_bank = True
     _block_cls = TransBlock
 
+    def late_gradient_parameters(self):
+        """Parameters whose gradient is complete only at the end of backward although they belong to late layers: the
+        members of the radial bank are evaluated at the start of the forward.  (Read by parallel.FlatGradAllReduce to lay
+        them out in the bucket that is reduced last.)"""
+        bank = self._radial_bank()
+        return [p for m in bank.modules for p in m.parameters()] if bank is not None else []
+
     def _attention_heads(self):
         """GraphAttention modules that read the final features (OC20 auxiliary / attention heads); none by default."""
         return []

@@ -10,8 +10,10 @@ base_trainer_v2.py:376-384) with torch's default 25 MB buckets and shards the da
     laid out in forward order and cut once into a HEAD part (embeddings + first blocks) and a TAIL part (last blocks +
     output head);
   * the TAIL part -- whose gradients are complete first, backward runs the layers in reverse -- is all-reduced
-    asynchronously from a gradient hook in the middle of backward, so that its RCCL collective overlaps the rest of
-    backward; the HEAD part follows when backward is done (`reduce()`);
+    asynchronously from the gradient hook of whichever tail parameter is completed last, in the middle of backward, so
+    that its RCCL collective overlaps the rest of backward; the HEAD part follows when backward is done (`reduce()`);
+    parameters of late layers whose gradient nevertheless arrives at the very end (the radial MLPs evaluated side by
+    side at the start of the forward) are laid out in the head part (`module.late_gradient_parameters()`);
   * molecules never interact (edges stay inside a molecule), so no other collective exists on the data path;
   * `shard_balanced` splits a batch over the ranks with near-equal sums of a per-molecule cost (edge count): the only
     scaling hazard of this path is the imbalance of the variable-size graphs.
@@ -29,7 +31,13 @@ class FlatGradAllReduce:
     hook during backward; 0 disables the hook (one collective in `reduce()`)."""
 
     def __init__(self, module, process_group=None, overlap=0.5):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        params = [p for p in module.parameters() if p.requires_grad]
+        # Layout = forward order, except that parameters whose gradient is only complete at the END of backward although
+        # they belong to late layers are moved to the front (the head bucket): a model says which ones through
+        # `late_gradient_parameters()` -- for the Equiformer trunk the radial MLPs of all blocks, which are evaluated side
+        # by side at the start of the forward (radial bank), so their backward node is among the last to run.
+        late = {id(p) for p in getattr(module, "late_gradient_parameters", lambda: [])()}
+        self.params = [p for p in params if id(p) in late] + [p for p in params if id(p) not in late]
         self.group = process_group
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
@@ -41,11 +49,12 @@ class FlatGradAllReduce:
             self.views.append(v)
             self.offsets.append(off)
             off += p.numel()
-        # cut: parameters [k, end) form the tail bucket; the trigger is the LAST parameter of the head bucket whose
-        # gradient appears once backward has passed the cut (autograd runs ready nodes latest-created first, so by
-        # then every node of the later layers, side branches included, has run)
+        # cut: parameters [k, end) form the tail bucket.  Every tail parameter reports its gradient through a
+        # post-accumulate hook; the collective is launched by whichever arrives LAST, in whatever order autograd runs the
+        # nodes.  (One backward() per reduce(): with several micro-batch backwards the first one would launch it.)
         self.split = len(self.params)
-        self._handle = None
+        self._handles = []
+        self._arrived = set()
         self._pending = None
         self._tail_done = False
         if overlap > 0 and len(self.params) > 1:
@@ -53,7 +62,7 @@ class FlatGradAllReduce:
             k = next((i for i, o in enumerate(self.offsets) if o >= want), len(self.params))
             k = min(max(k, 1), len(self.params) - 1)
             self.split = k
-            self._handle = self.params[k - 1].register_post_accumulate_grad_hook(self._on_trigger)
+            self._handles = [p.register_post_accumulate_grad_hook(self._on_tail_grad) for p in self.params[k:]]
 
     # ---------------------------------------------------------------------------------------------------------------
     def world_size(self):
@@ -82,12 +91,13 @@ class FlatGradAllReduce:
             return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), False
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), True
 
-    def _on_trigger(self, _param):
-        """Runs inside backward once the gradient of the last head-bucket parameter has been accumulated."""
+    def _on_tail_grad(self, param):
+        """Runs inside backward each time the gradient of a tail-bucket parameter has been accumulated."""
         if self._tail_done or self.world_size() == 1:
             return
-        if any(p.grad is None for p in self.params[self.split:]):
-            return  # a tail gradient is not there yet (unusual graph): fall back to the synchronous path in reduce()
+        self._arrived.add(id(param))
+        if len(self._arrived) < len(self.params) - self.split:
+            return
         self._pack(self.split, len(self.params))
         tail = self.flat[self.offsets[self.split]:]
         self._pending = self._all_reduce(tail, async_op=True)
@@ -110,6 +120,7 @@ class FlatGradAllReduce:
                 if need_div:
                     self.flat[self.offsets[self.split]:].div_(ws)
         self._pending, self._tail_done = None, False
+        self._arrived.clear()
         for p, v in zip(self.params, self.views):
             p.grad = v
         return self.flat

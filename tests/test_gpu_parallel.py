@@ -88,8 +88,12 @@ def test_two_rank_hip_model_flat_allreduce(tmp_path):
     model = _model(dev)
     d = qm9_like_batch(4, 10, side=5.0, seed=5)
     _loss(model, d, range(4), dev).backward()
-    full = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                      for p in model.parameters() if p.requires_grad]).cpu()
+    # the reducer lays the radial-bank parameters (late gradients) out first, the rest in forward order
+    late = {id(p) for p in model.late_gradient_parameters()}
+    assert late, "the trunk declares its radial bank"
+    params = [p for p in model.parameters() if p.requires_grad]
+    ordered = [p for p in params if id(p) in late] + [p for p in params if id(p) not in late]
+    full = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ordered]).cpu()
     err = ((full - r0["flat"]).abs().max() / full.abs().max()).item()
     assert err < 2e-5, err
 

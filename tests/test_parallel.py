@@ -92,6 +92,83 @@ def test_two_rank_gloo_flat_allreduce_matches_full_batch(tmp_path):
     assert err < 1e-5, err
 
 
+class _Toy(torch.nn.Module):
+    """Late layer (`z`, registered last) whose parameter is used FIRST in the forward: its gradient arrives last."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.a, self.b, self.c = (torch.nn.Linear(6, 6) for _ in range(3))
+        self.z = torch.nn.Linear(6, 6)
+        with torch.no_grad():
+            for p in self.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+        self.declare_late = True
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.b(torch.tanh(self.a(torch.tanh(self.z(x))))))).sum()
+
+    def late_gradient_parameters(self):
+        return list(self.z.parameters()) if self.declare_late else []
+
+
+def _toy_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from equiformer_amd.parallel import FlatGradAllReduce
+    res = {}
+    for declare in (True, False):
+        model = _Toy()
+        model.declare_late = declare
+        red = FlatGradAllReduce(model, overlap=0.5)
+        order = []
+        hooks = [p.register_post_accumulate_grad_hook(lambda p, n=n: order.append((n, bool(red._tail_done))))
+                 for n, p in model.named_parameters()]
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 + rank))
+        model(x).backward()
+        launched_after = next((i for i, (_, done) in enumerate(order) if done), None)  # hooks run in registration order
+        overlapped = bool(red._tail_done)
+        red.reduce()
+        names = [n for p in red.params for n, q in model.named_parameters() if q is p]
+        res[declare] = dict(names=names, overlapped=overlapped, launched_after=launched_after, arrivals=[n for n, _ in order],
+                            grads={n: p.grad.clone() for n, p in model.named_parameters()})
+        for h in hooks:
+            h.remove()
+    torch.save(res, os.path.join(out, "toy%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tail_bucket_is_launched_by_its_last_gradient_whatever_the_order(tmp_path):
+    """A late layer whose gradient arrives last: declared through late_gradient_parameters() it is laid out in the head
+    bucket and the tail's collective starts in the middle of backward; undeclared, the collective still starts from a
+    hook (when the straggler arrives) instead of falling back to the synchronous path.  Both average correctly."""
+    world = 2
+    mp.spawn(_toy_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "toy0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "toy1.pt"))
+    for declare in (True, False):
+        a, b = r0[declare], r1[declare]
+        assert a["overlapped"] and b["overlapped"]
+        assert a["arrivals"][-2:] == ["z.weight", "z.bias"] or set(a["arrivals"][-2:]) == {"z.weight", "z.bias"}
+        for n in a["grads"]:
+            assert torch.equal(a["grads"][n], b["grads"][n]), n
+        # reference: mean of the two ranks' local gradients
+        ref = {}
+        for rank in range(world):
+            m = _Toy()
+            m(torch.randn(5, 6, generator=torch.Generator().manual_seed(10 + rank))).backward()
+            for n, p in m.named_parameters():
+                ref[n] = ref.get(n, 0) + p.grad / world
+        for n in ref:
+            assert torch.allclose(a["grads"][n], ref[n], rtol=1e-6, atol=1e-7), n
+    assert r0[True]["names"][:2] == ["z.weight", "z.bias"] and r0[False]["names"][-2:] == ["z.weight", "z.bias"]
+    n = len(r0[True]["arrivals"])
+    assert r0[True]["launched_after"] < n - 2 <= r0[False]["launched_after"], (r0[True]["launched_after"], r0[False]["launched_after"])
+
+
 def test_shard_molecules_partitions_every_molecule_once():
     from equiformer_amd.parallel import shard_molecules
     for n in (0, 1, 7, 128, 1000):
