@@ -808,6 +808,11 @@ class Equiformer_MD17_DeNS(_Base):
                                                  Irreps("1x1e"), self.fc_neurons, irreps_head, num_heads,
                                                  irreps_pre_attn, rescale_degree, nonlinear_message, alpha_drop, proj_drop)
         self.apply(self._init_weights)
+        # module (= parameter) order of the reference [ref: :119-176]
+        order = ["atom_embed", "rbf", "edge_deg_embed", "force_embed", "blocks", "norm", "energy_head", "scale_scatter",
+                 "denoising_pos_head"]
+        assert sorted(order) == sorted(self._modules)
+        self._modules = {k: self._modules[k] for k in order}
 
     @torch.enable_grad()
     def forward(self, data):

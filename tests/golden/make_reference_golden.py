@@ -149,6 +149,66 @@ def main():
         e = rm(data)
         worst = max(worst, _report("oc20_small", dict(energy=e.detach().numpy()), outs, a.write))
 
+    # ---- the other families (make_golden.py --variants): dot-product attention, E(3) irreps, DeNS, OC20 auxiliary head
+    from nets.dp_attention_transformer import DotProductAttentionTransformer as RefDP  # [ref: :255-411]
+    from nets.dp_attention_transformer_md17 import DotProductAttentionTransformerMD17 as RefDPMD17  # [ref: :57-235]
+    from nets.equiformer_md17_dens import Equiformer_MD17_DeNS as RefDeNS  # [ref: :55-354]
+    # the dp / DeNS constructors of the reference take `nonlinear_message` etc. with their own defaults; the reduced
+    # configurations below only pass arguments every one of them accepts
+    ins, outs = _load("dp_qm9_small")
+    kw = dict(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **mg.SMALL_DP_L2)
+    om = fill_deterministic(onets.DotProductAttentionTransformer(**kw), 15)
+    rm = RefDP(**kw).double().eval()
+    _copy_by_name(om, rm)
+    e = rm(f_in=None, pos=torch.as_tensor(ins["pos"]).double(), batch=torch.as_tensor(ins["batch"]),
+           node_atom=torch.as_tensor(ins["z"]))
+    worst = max(worst, _report("dp_qm9_small", dict(energy=e.detach().numpy()), outs, a.write))
+
+    ins, outs = _load("dp_md17_small")
+    kw = dict(irreps_in="64x0e", max_radius=5.0, number_of_basis=32, basis_type="exp", **mg.SMALL_DP_L2)
+    om = fill_deterministic(onets.DotProductAttentionTransformerMD17(**kw), 19)
+    rm = RefDPMD17(**kw).double().eval()
+    _copy_by_name(om, rm)
+    e, f = rm(node_atom=torch.as_tensor(ins["z"]), pos=torch.as_tensor(ins["pos"]).double(), batch=torch.as_tensor(ins["batch"]))
+    worst = max(worst, _report("dp_md17_small", dict(energy=e.detach().numpy(), forces=f.detach().numpy()), outs, a.write))
+
+    ins, outs = _load("e3_qm9_small")
+    kw = dict(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **mg.SMALL_E3_L2)
+    om = fill_deterministic(onets.GraphAttentionTransformer(**kw), 16)
+    rm = RefQM9(**kw).double().eval()
+    _copy_by_name(om, rm)
+    e = rm(f_in=None, pos=torch.as_tensor(ins["pos"]).double(), batch=torch.as_tensor(ins["batch"]),
+           node_atom=torch.as_tensor(ins["z"]))
+    worst = max(worst, _report("e3_qm9_small", dict(energy=e.detach().numpy()), outs, a.write))
+
+    ins, outs = _load("dens_small")
+    om = fill_deterministic(onets.Equiformer_MD17_DeNS(**mg.SMALL_DENS), 18)
+    rm = RefDeNS(**mg.SMALL_DENS).double().eval()
+    _copy_by_name(om, rm)
+    data = SimpleNamespace(z=torch.as_tensor(ins["z"]), pos=torch.as_tensor(ins["pos"]).double(),
+                           batch=torch.as_tensor(ins["batch"]), force=torch.as_tensor(ins["force"]).double(),
+                           noise_mask=torch.as_tensor(ins["noise_mask"]))
+    e, dy = rm(data)
+    worst = max(worst, _report("dens_small", dict(energy=e.detach().numpy(), dy=dy.detach().numpy()), outs, a.write))
+
+    if RefOC20 is not None:
+        ins, outs = _load("oc20_aux_small")
+        kw = dict(mg.SMALL_OC20, number_of_basis=32, use_auxiliary_task=True, irreps_feature="64x0e+32x1e")
+        om = fill_deterministic(onets.GraphAttentionTransformerOC20(**kw), 17)
+        rm = RefOC20(None, None, 1, use_pbc=True, otf_graph=False, **kw).double().eval()
+        _copy_by_name(om, rm)
+        cell = 7.0
+        B = int(ins["batch"].max()) + 1
+        ei = torch.as_tensor(ins["edge_index"])
+        data = SimpleNamespace(pos=torch.as_tensor(ins["pos"]).double(), batch=torch.as_tensor(ins["batch"]),
+                               atomic_numbers=torch.as_tensor(ins["z"]), tags=torch.as_tensor(ins["tags"]), edge_index=ei,
+                               cell=(torch.eye(3) * cell)[None].repeat(B, 1, 1).double(),
+                               cell_offsets=torch.as_tensor(np.rint(ins["offsets"] / cell)).double(),
+                               neighbors=torch.bincount(torch.as_tensor(ins["batch"])[ei[1]], minlength=B),
+                               natoms=torch.bincount(torch.as_tensor(ins["batch"]), minlength=B))
+        e, aux = rm(data)
+        worst = max(worst, _report("oc20_aux_small", dict(energy=e.detach().numpy(), aux=aux.detach().numpy()), outs, a.write))
+
     print("worst relative difference oracle fixture vs reference: %.3e (tolerance %.0e)" % (worst, TOL))
     if not a.write and worst > TOL:
         raise SystemExit(1)

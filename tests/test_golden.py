@@ -87,6 +87,74 @@ def test_oracle_reproduces_oc20_fixture():
     assert _rel(e, outs["energy"]) < 1e-10
 
 
+# ---- the other model families (tests/golden/make_golden.py --variants): one table drives the CPU and the GPU tests
+def _variant_cases():
+    """name -> (oracle class, product (module, class), seed, constructor kwargs, kind)"""
+    return {
+        "dp_qm9_small": ("DotProductAttentionTransformer", ("dp_attention_transformer", "DotProductAttentionTransformer"), 15,
+                         dict(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **mg.SMALL_DP_L2), "qm9"),
+        "dp_md17_small": ("DotProductAttentionTransformerMD17",
+                          ("dp_attention_transformer", "DotProductAttentionTransformerMD17"), 19,
+                          dict(irreps_in="64x0e", max_radius=5.0, number_of_basis=32, basis_type="exp", **mg.SMALL_DP_L2),
+                          "md17"),
+        "e3_qm9_small": ("GraphAttentionTransformer", ("graph_attention_transformer", "GraphAttentionTransformer"), 16,
+                         dict(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **mg.SMALL_E3_L2), "qm9"),
+        "oc20_aux_small": ("GraphAttentionTransformerOC20",
+                           ("graph_attention_transformer_oc20", "GraphAttentionTransformerOC20"), 17,
+                           dict(mg.SMALL_OC20, number_of_basis=32, use_auxiliary_task=True, irreps_feature="64x0e+32x1e"),
+                           "oc20"),
+        "dens_small": ("Equiformer_MD17_DeNS", ("equiformer_md17_dens", "Equiformer_MD17_DeNS"), 18, dict(mg.SMALL_DENS),
+                       "dens"),
+    }
+
+
+def _run_variant(m, ins, kind, dev=None, dtype=torch.float32):
+    from types import SimpleNamespace
+    t = lambda k, dt=None: (torch.as_tensor(ins[k]).to(dt) if dt else torch.as_tensor(ins[k])).to(dev or "cpu")  # noqa: E731
+    if kind == "qm9":
+        return dict(energy=m(None, t("pos", dtype), t("batch"), t("z")))
+    if kind == "md17":
+        e, f = m(t("z"), t("pos", dtype), t("batch"))
+        return dict(energy=e, forces=f)
+    if kind == "oc20":
+        d = _oc20_inputs(ins, dev, dtype)
+        if dev is None:
+            e, a = m(**d)
+        else:
+            e, a = m(SimpleNamespace(**d))
+        return dict(energy=e, aux=a)
+    data = SimpleNamespace(z=t("z"), pos=t("pos", dtype), batch=t("batch"), force=t("force", dtype),
+                           noise_mask=t("noise_mask"))
+    e, dy = m(data)
+    return dict(energy=e, dy=dy)
+
+
+@pytest.mark.parametrize("name", sorted(_variant_cases()))
+def test_oracle_reproduces_variant_fixture(name):
+    from oracle import nets as onets
+    ocls, _, seed, kw, kind = _variant_cases()[name]
+    ins, outs = _load(name)
+    m = fill_deterministic(getattr(onets, ocls)(**kw).eval(), seed).double()
+    got = _run_variant(m, ins, kind, dtype=torch.float64)
+    for k in outs:
+        assert _rel(got[k], outs[k]) < 1e-9, (name, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(_variant_cases()))
+def test_hip_reproduces_variant_fixture(name):
+    _, (module, cls), seed, kw, kind = _variant_cases()[name]
+    ins, outs = _load(name)
+    kw = dict(kw)
+    if kind == "oc20":
+        m = _hip_model(cls, module, seed, num_atoms=None, bond_feat_dim=None, num_targets=1, **kw)
+    else:
+        m = _hip_model(cls, module, seed, **kw)
+    got = _run_variant(m, ins, kind, dev=torch.device("cuda:0"))
+    for k in outs:
+        assert _rel(got[k], outs[k]) < TOL, (name, k, _rel(got[k], outs[k]))
+
+
 # ------------------------------------------------------------------------------------------------- GPU: HIP path
 def _hip_model(cls_name, module, seed, **kw):
     import importlib

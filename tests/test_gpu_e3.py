@@ -16,9 +16,9 @@ from oracle import nets as onets
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 from weights import fill_deterministic  # noqa: E402
 
-SMALL_E3_L2 = dict(irreps_node_embedding="32x0e+16x0o+16x1e+16x1o+8x2e+8x2o", num_layers=2, irreps_sh="1x0e+1x1o+1x2e",
-                   fc_neurons=[64, 64], irreps_feature="64x0e", irreps_head="8x0e+4x0o+4x1e+4x1o+4x2e+4x2o", num_heads=4,
-                   nonlinear_message=True, irreps_mlp_mid="64x0e+16x0o+32x1e+16x1o+16x2e+16x2o", alpha_drop=0.0)
+import make_golden as mg  # noqa: E402
+
+SMALL_E3_L2 = mg.SMALL_E3_L2
 SMALL_E3_L3 = dict(irreps_node_embedding="32x0e+16x0o+16x1e+16x1o+8x2e+8x2o+8x3e+8x3o", num_layers=2,
                    irreps_sh="1x0e+1x1o+1x2e+1x3o", fc_neurons=[64, 64], irreps_feature="64x0e",
                    irreps_head="8x0e+4x0o+4x1e+4x1o+4x2e+4x2o+4x3e+4x3o", num_heads=4, nonlinear_message=True,
