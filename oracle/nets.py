@@ -16,7 +16,14 @@ Op-for-op restatement, in plain torch (fp32 or fp64, CPU), of the model classes 
   nets/radial_func.py                      RadialProfile :9-49
   nets/gaussian_rbf.py                     gaussian :5-9, GaussianRadialBasisLayer :13-40
   nets/graph_attention_transformer_md17.py CosineCutoff :51-81, ExpNormalSmearing :85-124, model :127-327, factories :407-442
-  nets/graph_attention_transformer_oc20.py energy path of GraphAttentionTransformerOC20 :85-381 (non-PBC / precomputed-edge form)
+  nets/graph_attention_transformer_oc20.py GraphAttentionTransformerOC20 :85-381 (precomputed-edge form): energy head on the
+                                           scalar channels :169-179, auxiliary IS2RS head :182-194, attention head + skip
+                                           :196-208, forward :305-381
+  nets/drop.py                             drop_path :13-29, GraphDropPath :45-61 (inside TransBlock)
+  nets/dp_attention_transformer*.py        ScaleFactor :45-66, DotProductAttention :68-160, DPTransBlock :163-252 and the
+                                           three model classes (QM9, MD17, OC20)
+  nets/equiformer_md17_dens.py             Equiformer_MD17_DeNS :55-354 (force encoding, energy head, denoising head)
+  ocpmodels gemnet layers (un-vendored)    SphericalBesselBasis / polynomial Envelope / RadialBasis as called by :785-787
 
 Third-party ops restated: torch_cluster.radius_graph (1.6.0), torch_scatter.scatter (2.0.9),
 torch_geometric.utils.softmax / nn.inits.glorot (2.0.3).
