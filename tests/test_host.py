@@ -32,6 +32,25 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert not (dev & set(lib.SIGNATURES)), "development switches must stay out of the product's binding table"
 
 
+def test_binding_table_matches_header_prototypes():
+    """Every ctypes signature has as many arguments as the C prototype it binds (the table is written by hand)."""
+    import re
+    from equiformer_amd import lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "equiformer_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {m.group(1): m.group(2) for m in re.finditer(r"\bint\s+(eqf_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)}
+    assert len(protos) > 60
+    checked = 0
+    for name, argtypes in lib.SIGNATURES.items():
+        assert name in protos, name
+        args = protos[name].strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        assert n == len(argtypes), (name, n, len(argtypes))
+        checked += 1
+    assert checked == len(lib.SIGNATURES) and checked > 60
+
+
 def test_struct_layouts_match_header():
     from equiformer_amd import lib
     assert ctypes.sizeof(lib.EqfIrreps) == 4 * (1 + 3 * lib.EQF_MAX_SEG)  # nseg, l[], mul[], odd[]
