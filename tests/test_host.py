@@ -244,6 +244,37 @@ def test_dtp_table_matches_oracle_instructions():
     assert DtpTable("128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "128x0e+64x1e+32x2e").m_numel == 179
 
 
+def test_dtp_table_with_parity_matches_oracle_instructions():
+    """E(3) irreps: paths keyed on (degree, parity); spherical harmonics carry (-1)^l; only 0e is forced."""
+    from equiformer_amd.layout import DtpTable
+    from oracle import nets as onets
+    cases = [("128x0e+32x0o+32x1e+32x1o+16x2e+16x2o", "1x0e+1x1o+1x2e", 30),
+             ("128x0e+64x0o+32x1e+32x1o+32x2e+32x2o+16x3e+16x3o", "1x0e+1x1o+1x2e+1x3o", 68),
+             ("256x0e+64x0o+64x1e+64x1o", "1x0e+1x1o", 10)]
+    for irr, sh, npaths in cases:
+        t = DtpTable(irr, sh, irr)
+        o = onets.DepthwiseTensorProduct(irr, sh, irr, bias=False)
+        assert len(t.paths) == len(o.tp.instructions) == npaths and t.weight_numel == o.tp.weight_numel
+        assert repr(t.irreps_out) == repr(o.irreps_out.simplify())
+        assert repr(t.irreps_out_unsimplified) == repr(o.irreps_out)
+        assert t.has_odd and not t.fusable
+        slices = o.irreps_out.slices()
+        simp = list(o.irreps_out.simplify())
+        for p, (i1, i2, io, *_rest) in zip(t.paths, o.tp.instructions):
+            ir1, ir2, iro = o.irreps_in1[i1][1], o.irreps_in2[i2][1], o.irreps_out[io][1]
+            assert (p["l1"], p["l2"], p["l3"], p["p3"]) == (ir1.l, ir2.l, iro.l, iro.p) and iro.p == ir1.p * ir2.p
+            seg_start = 0
+            for m, ir in simp:
+                if (ir.l, ir.p) == (iro.l, iro.p):
+                    break
+                seg_start += m * ir.dim
+            assert p["out_off"] == seg_start
+            assert slices[io].start == seg_start + p["out_ch"] * (2 * p["l3"] + 1)
+    # an SE(3)-flavoured table (all-even harmonics) couples 1e x 1e -> 1e; the E(3) one sends 1o x 1o to 1e, never to 1o
+    e3 = DtpTable("8x1o", "1x0e+1x1o", "8x0e+8x1e+8x1o")
+    assert sorted((p["l2"], p["l3"], p["p3"]) for p in e3.paths) == [(0, 1, -1), (1, 0, 1), (1, 1, 1)]
+
+
 def test_so3_matches_oracle_and_constants():
     import numpy as np
     from equiformer_amd import so3

@@ -155,6 +155,63 @@ def test_oc20_heads_are_equivariant_and_drop_path_is_per_graph():
     assert torch.equal(blk.eval()._drop_path(x, batch), x)
 
 
+def test_other_families_o3_and_permutation_invariances():
+    """Oracle restatements added in round 2: dot-product attention [ref: nets/dp_attention_transformer.py], E(3) irreps
+    (the `_e3` factories) and DeNS [ref: nets/equiformer_md17_dens.py] -- energies invariant under rotations, translations
+    and atom permutations; the E(3) model also under INVERSION; forces / denoising vectors rotate (and flip under
+    inversion); the DeNS force encoding rotates with its input."""
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(8)
+    B, Na = 2, 8
+    pos = torch.rand(B * Na, 3, generator=g, dtype=torch.float64) * 3.5
+    batch = torch.arange(B).repeat_interleave(Na)
+    z_q = torch.tensor([1, 6, 7, 8, 9])[torch.randint(0, 5, (B * Na,), generator=g)]
+    z_m = torch.randint(1, 9, (B * Na,), generator=g)
+    R = _rot(g)
+    perm = torch.cat([torch.randperm(Na, generator=g), torch.arange(Na, B * Na)])
+    base = dict(num_layers=2, max_radius=5.0, number_of_basis=16, fc_neurons=[16, 16], irreps_feature="32x0e", num_heads=2)
+    so3 = dict(irreps_node_embedding="16x0e+8x1e+4x2e", irreps_sh="1x0e+1x1e+1x2e", irreps_head="8x0e+4x1e+2x2e",
+               irreps_mlp_mid="16x0e+8x1e+4x2e")
+    e3 = dict(irreps_node_embedding="16x0e+4x0o+4x1e+4x1o+2x2e+2x2o", irreps_sh="1x0e+1x1o+1x2e",
+              irreps_head="8x0e+2x0o+2x1e+2x1o+2x2e+2x2o", irreps_mlp_mid="16x0e+4x0o+4x1e+4x1o+2x2e+2x2o")
+    # --- dot-product attention, energy model
+    torch.manual_seed(0)
+    m = nets.DotProductAttentionTransformer(irreps_in="5x0e", alpha_drop=0.0, **base, **so3).double().eval()
+    y = m(None, pos, batch, z_q)
+    assert (y - m(None, pos @ R.T + 0.3, batch, z_q)).abs().max() < 1e-10
+    assert (y - m(None, pos[perm], batch[perm], z_q[perm])).abs().max() < 1e-10
+    # --- E(3) irreps: rotation AND inversion; forces are polar vectors
+    torch.manual_seed(0)
+    m = nets.GraphAttentionTransformerMD17(irreps_in="64x0e", basis_type="exp", nonlinear_message=True, alpha_drop=0.0,
+                                           **base, **e3).double().eval()
+    E, F = m(z_m, pos.clone(), batch)
+    E2, F2 = m(z_m, (pos @ R.T).clone(), batch)
+    E3, F3 = m(z_m, (-pos).clone(), batch)
+    assert (E - E2).abs().max() < 1e-10 and (F2 - F @ R.T).abs().max() < 1e-9
+    assert (E - E3).abs().max() < 1e-10 and (F3 + F).abs().max() < 1e-9
+    assert F.abs().max() > 1e-4
+    # the SO(3)-flavoured model (all-even harmonics) is NOT inversion invariant: parity is what the E(3) variant adds
+    torch.manual_seed(0)
+    ms = nets.GraphAttentionTransformerMD17(irreps_in="64x0e", basis_type="exp", nonlinear_message=True, alpha_drop=0.0,
+                                            **base, **so3).double().eval()
+    Es, _ = ms(z_m, pos.clone(), batch)
+    Ei, _ = ms(z_m, (-pos).clone(), batch)
+    assert (Es - Ei).abs().max() > 1e-8
+    # --- DeNS: energy invariant, output vectors (forces on clean atoms, denoising vectors on corrupted ones) rotate
+    torch.manual_seed(0)
+    md = nets.Equiformer_MD17_DeNS(irreps_feature="32x0e+16x1e+8x2e", irreps_pre_attn="16x0e+8x1e+4x2e",
+                                   irreps_equivariant_inputs="1x0e+1x1e+1x2e", nonlinear_message=True, alpha_drop=0.0,
+                                   **{k: v for k, v in base.items() if k != "irreps_feature"}, **so3).double().eval()
+    force = torch.randn(B * Na, 3, generator=g, dtype=torch.float64)
+    mask = torch.rand(B * Na, generator=g) < 0.4
+    assert mask.any() and (~mask).any()
+    e, dy = md(SimpleNamespace(z=z_m, pos=pos.clone(), batch=batch, force=force, noise_mask=mask))
+    e2, dy2 = md(SimpleNamespace(z=z_m, pos=(pos @ R.T).clone(), batch=batch, force=force @ R.T, noise_mask=mask))
+    assert (e - e2).abs().max() < 1e-10 and (dy2 - dy @ R.T).abs().max() < 1e-9
+    e3_, _ = md(SimpleNamespace(z=z_m, pos=pos.clone(), batch=batch, force=2.0 * force, noise_mask=mask))
+    assert (e - e3_).abs().max() > 1e-8  # the encoded forces do reach the energy
+
+
 def test_kat6_kat7_md17_forces():
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(5)
