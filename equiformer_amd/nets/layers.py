@@ -383,7 +383,8 @@ class SeparableFCTP(nn.Module):
         self.lin = LinearRS(self.dtp.table.irreps_out, irreps_lin_output)
         self.norm = None
         self.gate = make_gate(self.irreps_node_output) if use_activation else None
-        self.fused_spec = ops.DtpLinearSpec(self.dtp.table, self.lin.layout_out) if self.dtp.table.fusable else None
+        self.fused_spec = (ops.DtpLinearSpec(self.dtp.table, self.lin.layout_out)
+                           if self.dtp.table.fusable and not self.lin.layout_out.has_odd else None)
         self.sfc_spec = ops.SfcSpec(self.dtp.table, self.lin.layout_out)
         if internal_weights:
             # row (path, channel) of the stacked lin weight -> index of its shared DTP weight
@@ -488,7 +489,7 @@ class GraphAttention(nn.Module):
                                            fc_neurons=None, use_activation=False, norm_layer=None,
                                            internal_weights=True)
             self.alpha_fused_spec = (ops.DtpLinearSpec(self.sep_act.dtp.table, self.sep_alpha.layout_out)
-                                     if self.sep_act.dtp.table.fusable else None)
+                                     if self.sep_act.dtp.table.fusable and not self.sep_alpha.layout_out.has_odd else None)
             # value linear + attention-logit linear share ONE generation of the DTP output (concatenated degree-0
             # weight)
             self.act_sfc_spec = ops.SfcSpec(self.sep_act.dtp.table, self.sep_act.lin.layout_out, n2=mul_alpha)

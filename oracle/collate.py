@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE (oracle): PyG 2.0.3 `Batch.from_data_list` collation rules, written as plain loops.
 
 The reference batches with torch_geometric.loader.DataLoader (main_qm9.py:9,204-216); torch_geometric is an
-un-vendored dependency that cannot be imported here (**parity unpinned**), so this restates its documented rules:
+un-vendored dependency that cannot be imported here (dependency restatement, collation is not on the arithmetic path), so this restates its documented rules:
 tensors are concatenated along dim 0, except attributes whose name contains "index", which are concatenated along the
 last dim after adding the number of nodes of the preceding graphs; `batch[i]` = graph of node i; `ptr` = node offsets.
 """

@@ -1,9 +1,10 @@
 """ORACLE (test infrastructure, NOT product code) -- e3nn-0.4.4 semantics restated in plain torch.
 
-PARITY UNPINNED: the reference (atomicarchitects/equiformer) ships no golden vectors and its
-arithmetic lives in the un-vendored dependency e3nn==0.4.4 (env/env_equiformer.yml:358), which is not
-installable in this container.  This file restates e3nn's *published* algorithms for the four things
-the hot path uses, anchored on the reference's call sites:
+DEPENDENCY RESTATEMENT: the reference's arithmetic primitives live in the un-vendored dependency e3nn==0.4.4
+(env/env_equiformer.yml:358), which is not installable in this container.  This file restates e3nn's *published*
+algorithms for the things the hot path uses, anchored on the reference's call sites.  The reference's MODEL code is
+executed on top of these primitives by oracle/refshim (tests/test_reference_pin.py); the primitives themselves are
+pinned by answers that do not come from this code base (tests/test_independent_kat.py) -- see oracle/__init__.py.
 
   * ``o3.Irreps`` algebra                       (call sites: nets/graph_attention_transformer.py:765-779)
   * ``o3.wigner_3j`` (real basis)               (used inside o3.TensorProduct; nets/tensor_product_rescale.py:33-37)

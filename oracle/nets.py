@@ -1,6 +1,7 @@
 """ORACLE (test infrastructure, NOT product code) -- CPU restatement of the Equiformer hot path.
 
-PARITY UNPINNED (see oracle/e3.py header): the reference cannot be imported here and holds no golden vectors.
+PINNED against the reference's own model code: tests/test_reference_pin.py imports /root/reference/nets unchanged
+(oracle/refshim) and finds every family of this file equal to it in fp64 (<= 1e-9) with weights copied by name.
 Op-for-op restatement, in plain torch (fp32 or fp64, CPU), of the model classes of the reference
 (paths relative to /root/reference):
 
@@ -453,8 +454,10 @@ class DotProductAttention(nn.Module):
         self.proj = LinearRS(heads_all, Irreps(irreps_node_output))
         # ScaleFactor: 1/sqrt(number of irreps of a head) per channel, 1/sqrt(2l+1) per irrep
         chan = 1.0 / (self.irreps_head.num_irreps ** 0.5)
-        self.register_buffer("_q_scale", torch.cat([torch.full((mul * ir.dim,), chan / ir.dim ** 0.5)
-                                                    for mul, ir in self.irreps_head]), persistent=False)
+        # plain fp64 attribute, not a buffer: Module.double() of an fp32-built model must not leave an fp32-rounded scale
+        # (the reference multiplies by Python floats, :58-62; found by tests/test_reference_pin.py: 3e-9 / 3e-8)
+        self._q_scale = torch.cat([torch.full((mul * ir.dim,), chan / ir.dim ** 0.5, dtype=torch.float64)
+                                   for mul, ir in self.irreps_head])
 
     def forward(self, node_input, edge_src, edge_dst, edge_attr, edge_scalars):
         q = vec2heads(self.query(node_input), self.irreps_head, self.num_heads) * self._q_scale.to(node_input.dtype)

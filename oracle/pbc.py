@@ -3,7 +3,7 @@
 The reference calls `radius_graph_pbc(data, max_radius, max_neighbors)` and `get_pbc_distances(pos, edge_index, cell,
 cell_offsets, neighbors, return_offsets=True)` (nets/graph_attention_transformer_oc20.py:267-293).  Both live in the
 un-vendored dependency ocpmodels 0.0.3 @ d2aaaeb (docs/env_setup.md:18-26 of the reference), file
-ocpmodels/common/utils.py, which is absent from /root/reference and cannot be installed here.  **Parity unpinned**:
+ocpmodels/common/utils.py, which is absent from /root/reference and cannot be installed here.  Dependency restatement (ocpmodels itself has never run here):
 what follows restates that library's published algorithm; it is anchored on the reference's own call sites (argument
 meaning, the edge_vec = pos[src] - pos[dst] + offsets convention of :290-291) and on the known-answer tests in
 tests/test_oracle_kat.py (coordination numbers of simple lattices).

@@ -1,13 +1,12 @@
 #!/usr/bin/env python
-"""Generate the golden fixtures of tests/golden/ (run from the repo root:  python tests/golden/make_golden.py).
+"""Inputs and model configurations of the golden fixtures of tests/golden/ (python tests/golden/make_golden.py).
 
-What they pin.  The reference (atomicarchitects/equiformer) cannot be imported in this container (e3nn, PyG,
-torch_scatter, torch_cluster are absent and un-installable) and ships no golden vectors, so these fixtures are NOT
-outputs of the reference itself: they are outputs of the CPU oracle (oracle/, fp64) on fixed inputs and fixed weights
-(tests/golden/weights.py: numpy PCG64 stream, independent of torch's RNG).  They freeze the oracle (any later edit that changes its arithmetic fails tests/test_golden.py on
-CPU) and give the GPU tests a target that does not depend on torch's RNG stream.  Parity of the oracle with the
-reference stays "unpinned" in the sense of DESIGN.md; the conventions are pinned by the known-answer tests in
-tests/test_oracle_kat.py instead.
+Two steps make a fixture.  (1) This script fixes the inputs, the reduced model configurations (SMALL_*) and -- through
+tests/golden/weights.py (numpy PCG64 stream, independent of torch's RNG) -- the weights, and stores the CPU oracle's fp64
+outputs.  (2) tests/golden/make_reference_golden.py --write re-computes every output with the REFERENCE'S OWN model code
+(/root/reference/nets imported unchanged, dependency stand-ins from oracle/refshim) and overwrites the out:: arrays; the
+committed .npz files are the result of step 2.  tests/test_reference_pin.py re-checks them against the reference on
+every CPU run in the build container, tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 
 Models are reduced copies of the BASELINE configs (2 blocks, 32-channel degrees, 64 scalar features) so that a fixture
 is a few kB; all code paths (radius graph, SH, RBF, radial MLP, DTP, gate, attention, layer norm, FFN with
