@@ -3,9 +3,9 @@
 The reference registers the class in ocpmodels' registry as "graph_attention_transformer" and receives an ocpmodels
 `Batch`; ocpmodels is un-vendored, so the class is exposed here under the same name through this package's registry
 (`oc20_graph_attention_transformer`) and accepts any object with the same attributes
-(`pos, batch, atomic_numbers, tags, natoms`, and for periodic inputs either `cell` -- the neighbour search then runs
-on the GPU (`EdgeGraph.from_radius_pbc`, the `otf_graph=True` path of the YAML config) -- or a precomputed `edge_index` +
-per-edge Cartesian `offsets` as radius_graph_pbc / get_pbc_distances produce upstream).  The auxiliary IS2RS head
+(`pos, batch, atomic_numbers, tags, natoms, cell`, and with `otf_graph=False` the precomputed `edge_index, cell_offsets,
+neighbors` of an ocpmodels batch -- see `_graph` for the exact contract; with `otf_graph=True` the periodic neighbour search
+runs on the GPU, `EdgeGraph.from_radius_pbc`).  The auxiliary IS2RS head
 (`use_auxiliary_task`, the `*_aux_*` configs), the attention head (`use_attention_head`) and per-graph stochastic depth
 (`drop_path_rate`) are built as upstream; atom-edge attributes and node attributes are used by no shipped config and are
 rejected.
@@ -50,7 +50,8 @@ class GraphAttentionTransformerOC20(_Trunk):
                                         Activation(scalars, kind="silu"),
                                         LinearRS(scalars, Irreps("1x0e")))
         self.use_auxiliary_task, self.use_attention_head = use_auxiliary_task, use_attention_head
-        irreps_aux = Irreps("1x1e")  # the SO(3) variants carry no 1o feature [ref: :185-187]
+        # [ref: :185-187] 1o when the feature carries 1o channels (E(3) variants), 1e otherwise
+        irreps_aux = Irreps("1x1o") if any(ir.l == 1 and ir.p == -1 for _, ir in self.irreps_feature) else Irreps("1x1e")
         head_drop = alpha_drop if auxiliary_head_dropout else 0.0
 
         def attention(irreps_out):
@@ -63,6 +64,12 @@ class GraphAttentionTransformerOC20(_Trunk):
             self.head = attention(irreps_out)
             self.head_skip_connect = LinearRS(self.irreps_feature, irreps_out)
         self.apply(self._init_weights)
+        # registration order of the reference (tag_embed right after atom_embed, :146-147): parameters() order is what
+        # optimizer checkpoints index by (tests/test_reference_pin.py)
+        mods = dict(self._modules)
+        tag = mods.pop("tag_embed")
+        self._modules = {k2: v2 for k, v in mods.items() for k2, v2 in (((k, v), ("tag_embed", tag)) if k == "atom_embed"
+                                                                         else ((k, v),))}
 
     def _head_attention(self, irreps_out, num_heads, irreps_pre_attn, rescale_degree, nonlinear_message, alpha_drop):
         return GraphAttention(self.irreps_feature, self.irreps_node_attr, self.irreps_edge_attr, irreps_out,
@@ -74,26 +81,60 @@ class GraphAttentionTransformerOC20(_Trunk):
             return [self.head]
         return [self.auxiliary_head] if self.use_auxiliary_task else []
 
+    def _graph(self, data, pos, batch):
+        """The reference's input contract [ref: _forward_otf_graph :267-277, _forward_use_pbc :280-302]:
+
+        * otf_graph=True: the graph is REBUILT from positions (and data.cell when use_pbc) even if the batch carries a
+          precomputed edge_index -- on the GPU here (EdgeGraph.from_radius_pbc = radius_graph_pbc + get_pbc_distances);
+        * otf_graph=False, use_pbc=True: the ocpmodels batch's data.edge_index [2,E] (neighbour, centre) +
+          data.cell_offsets [E,3] (integer images) + data.neighbors [B] (edges per structure) + data.cell [B,3,3];
+          Cartesian offsets = cell_offsets @ cell[structure of the edge], zero-length edges dropped
+          (get_pbc_distances(return_offsets=True));
+        * use_pbc=False: plain radius graph from positions (a precomputed edge_index is ignored, as upstream).
+
+        Extension (not in the reference): with otf_graph=False and no data.cell_offsets, per-edge Cartesian
+        `data.offsets` [E,3] next to data.edge_index are taken as they are."""
+        if not self.use_pbc:
+            return EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=self.max_neighbors), None
+        if self.otf_graph:
+            cell = getattr(data, "cell", None)
+            if cell is None:
+                raise ValueError("otf_graph=True with use_pbc=True needs data.cell ([B,3,3])")
+            graph, offsets, _ = EdgeGraph.from_radius_pbc(pos, cell, batch, self.max_radius,
+                                                          max_num_neighbors=self.max_neighbors)
+            return graph, offsets
+        edge_index = getattr(data, "edge_index", None)
+        cell_offsets = getattr(data, "cell_offsets", None)
+        if edge_index is None:
+            raise ValueError("otf_graph=False with use_pbc=True needs data.edge_index + data.cell_offsets + data.neighbors "
+                             "+ data.cell (the ocpmodels batch), or otf_graph=True")
+        edge_index = edge_index.to(pos.device)
+        if cell_offsets is not None:
+            cell, neighbors = getattr(data, "cell", None), getattr(data, "neighbors", None)
+            if cell is None or neighbors is None:
+                raise ValueError("data.cell_offsets needs data.cell ([B,3,3]) and data.neighbors ([B])")
+            cell = cell.to(device=pos.device, dtype=torch.float32).view(-1, 3, 3)
+            per_edge = torch.repeat_interleave(cell, neighbors.to(pos.device).long(), dim=0)
+            if per_edge.shape[0] != edge_index.shape[1]:
+                raise ValueError("data.neighbors sums to %d, data.edge_index has %d edges"
+                                 % (per_edge.shape[0], edge_index.shape[1]))
+            offsets = torch.bmm(cell_offsets.to(device=pos.device, dtype=torch.float32).view(-1, 1, 3), per_edge).view(-1, 3)
+            vec = pos.detach()[edge_index[0]] - pos.detach()[edge_index[1]] + offsets
+            keep = (vec != 0).any(dim=1)  # get_pbc_distances drops zero-length edges
+            if not bool(keep.all()):
+                edge_index, offsets = edge_index[:, keep], offsets[keep]
+        else:
+            offsets = getattr(data, "offsets", None)
+            if offsets is None:
+                raise ValueError("use_pbc=True: data.edge_index without data.cell_offsets (ocpmodels) or data.offsets")
+            offsets = offsets.to(device=pos.device, dtype=torch.float32)
+        graph, order = EdgeGraph.from_edges(edge_index[0], edge_index[1], pos.shape[0], batch)
+        return graph, offsets[order].contiguous()
+
     def forward(self, data):
         pos = data.pos.to(torch.float32).contiguous()
         batch = data.batch
-        offsets = None
-        edge_index = getattr(data, "edge_index", None)
-        if edge_index is not None:
-            graph, order = EdgeGraph.from_edges(edge_index[0], edge_index[1], pos.shape[0], batch)
-            off = getattr(data, "offsets", None)
-            if off is not None:
-                offsets = off.to(torch.float32)[order].contiguous()
-        else:
-            # otf_graph [ref: _forward_otf_graph / _forward_use_pbc, :267-302]
-            if self.use_pbc:
-                cell = getattr(data, "cell", None)
-                if cell is None:
-                    raise ValueError("use_pbc=True needs data.cell ([B,3,3]) or precomputed data.edge_index / offsets")
-                graph, offsets, _ = EdgeGraph.from_radius_pbc(pos, cell, batch, self.max_radius,
-                                                              max_num_neighbors=self.max_neighbors)
-            else:
-                graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=self.max_neighbors)
+        graph, offsets = self._graph(data, pos, batch)
         atom_embedding, _, _ = self.atom_embed(data.atomic_numbers.long())
         tag_embedding, _, _ = self.tag_embed(data.tags.long())
         node_features, ectx = self._trunk_features(atom_embedding + tag_embedding, pos, graph, offsets)

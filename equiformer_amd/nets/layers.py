@@ -409,6 +409,9 @@ class SeparableFCTP(nn.Module):
                 starts.extend(range(o, o + K * N, N))
                 o += K * N
             starts.append(o)
+            # eqf_fold_weight_* pair row r of the flat lin weight with shared weight idx[r] and WRITE dw[idx[r]] (no
+            # accumulation): rows and shared weights must correspond one to one (every DTP output segment has its pair)
+            assert len(starts) - 1 == len(idx) and len(set(idx)) == len(idx), (len(starts) - 1, len(idx))
             self.register_buffer("_row_start", torch.tensor(starts, dtype=torch.int32), persistent=False)
             self.register_buffer("_w_of_row", torch.tensor(idx, dtype=torch.int32), persistent=False)
 

@@ -20,7 +20,17 @@ class HipOnlyError(RuntimeError):
 
 
 _dummy = {}
-_input_grads_only = [False]
+
+
+class _Flag:
+    on = False
+
+
+# PROCESS-global on purpose, not thread-local: autograd executes the backward of GPU operators on its per-device worker
+# thread, not on the thread that called autograd.grad(), so a threading.local set by the caller would be invisible to the
+# very backward it is meant for.  The assumption is the reference's: one Python thread drives one model per process
+# (one process per GPU); two threads running force passes and training backwards concurrently are not supported.
+_input_grads_only = _Flag()
 
 
 class input_grads_only:
@@ -31,16 +41,16 @@ class input_grads_only:
     (first-order kernels; differentiating THROUGH those raises)."""
 
     def __enter__(self):
-        self.prev = _input_grads_only[0]
-        _input_grads_only[0] = True
+        self.prev = _input_grads_only.on
+        _input_grads_only.on = True
 
     def __exit__(self, *exc):
-        _input_grads_only[0] = self.prev
+        _input_grads_only.on = self.prev
         return False
 
 
 def _want_param_grads():
-    return not _input_grads_only[0]
+    return not _input_grads_only.on
 
 
 def _guard_opt(t, dep, what):

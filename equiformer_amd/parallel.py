@@ -57,6 +57,7 @@ class FlatGradAllReduce:
         self._arrived = set()
         self._pending = None
         self._tail_done = False
+        self._accumulate = False
         if overlap > 0 and len(self.params) > 1:
             want = n * (1.0 - overlap)
             k = next((i for i, o in enumerate(self.offsets) if o >= want), len(self.params))
@@ -91,10 +92,29 @@ class FlatGradAllReduce:
             return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op), False
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), True
 
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward() passes inside it only accumulate into .grad (the hook is
+        off); the LAST micro-batch runs outside it, followed by reduce().  [ref: DistributedDataParallel.no_sync]"""
+        outer = self
+
+        class _NoSync:
+            def __enter__(self):
+                outer._accumulate = True
+
+            def __exit__(self, *exc):
+                outer._accumulate = False
+                return False
+        return _NoSync()
+
     def _on_tail_grad(self, param):
         """Runs inside backward each time the gradient of a tail-bucket parameter has been accumulated."""
-        if self._tail_done or self.world_size() == 1:
+        if self.world_size() == 1 or self._accumulate:
             return
+        if self._tail_done:
+            # the tail collective of this step is already in flight: a second backward() would accumulate into gradients
+            # that are being (or have been) averaged, silently diverging the ranks
+            raise RuntimeError("FlatGradAllReduce: backward() ran again before reduce(); wrap all but the last "
+                               "micro-batch in no_sync()")
         self._arrived.add(id(param))
         if len(self._arrived) < len(self.params) - self.split:
             return
@@ -104,13 +124,21 @@ class FlatGradAllReduce:
         self._tail_done = True
 
     def reduce(self):
-        """Call after backward(): finishes the average of the flat gradient (waits for the collective launched during
-        backward, reduces the rest) and re-points each .grad at its slice of the buffer (no copy back)."""
+        """Call after backward(): finishes the average of the flat gradient and re-points each .grad at its slice of the
+        buffer (no copy back).  The collective SEQUENCE is the same on every rank whatever happened in backward: always
+        all_reduce(tail) then all_reduce(head) when the buffer is split.  If the hook did not launch the tail on this rank
+        (a tail parameter received no gradient here: an unused branch, a batch without edges), the tail is packed and
+        launched now -- a rank that fell back to ONE collective over the whole buffer would pair its collective with
+        another rank's tail collective (mismatched sizes: hang or corruption)."""
         ws = self.world_size()
-        n_head = self.split if self._tail_done else len(self.params)
-        self._pack(0, n_head)
+        split = self.split < len(self.params)
+        if not self._tail_done:
+            self._pack(self.split, len(self.params))
+            if ws > 1 and split:
+                self._pending = self._all_reduce(self.flat[self.offsets[self.split]:], async_op=True)
+        self._pack(0, self.split)
         if ws > 1:
-            head = self.flat[:self.offsets[self.split]] if self._tail_done else self.flat
+            head = self.flat[:self.offsets[self.split]] if split else self.flat
             _, need_div_head = self._all_reduce(head, async_op=False)
             if need_div_head:
                 head.div_(ws)

@@ -746,7 +746,7 @@ class GraphAttentionTransformerOC20(_Base):
                                   Activation(scalars, [torch.nn.functional.silu]),
                                   LinearRS(scalars, Irreps("1x0e")))
         self.use_auxiliary_task, self.use_attention_head = use_auxiliary_task, use_attention_head
-        irreps_aux = Irreps("1x1e")  # SO(3) variants carry no 1o [ref: :185-187]
+        irreps_aux = Irreps("1x1o") if Irrep("1o") in self.irreps_feature else Irreps("1x1e")  # [ref: :185-187]
         head_drop = alpha_drop if auxiliary_head_dropout else 0.0
 
         def attention(irreps_out):
@@ -764,6 +764,11 @@ class GraphAttentionTransformerOC20(_Base):
             self.head = attention(irreps_out)
             self.head_skip_connect = LinearRS(self.irreps_feature, irreps_out)
         self.apply(self._init_weights)
+        # registration order of the reference: tag_embed right after atom_embed [ref: :146-147]
+        mods = dict(self._modules)
+        tag = mods.pop("tag_embed")
+        self._modules = {k2: v2 for k, v in mods.items() for k2, v2 in (((k, v), ("tag_embed", tag)) if k == "atom_embed"
+                                                                         else ((k, v),))}
 
     def forward(self, atomic_numbers, tags, pos, batch, edge_index=None, offsets=None):
         if edge_index is None:

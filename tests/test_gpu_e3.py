@@ -176,7 +176,7 @@ def test_e3_registered_models_full_width():
                 irreps_head="32x0e+8x0o+8x1e+8x1o", irreps_pre_attn="256x0e+64x0o+64x1e+64x1o",
                 irreps_mlp_mid="768x0e+192x0o+192x1e+192x1o")
     ref = onets.oc20_l1_256_nonlinear(**over).double().eval()
-    mod = nets.model_entrypoint("oc20_l1_256_e3_nonlinear")(num_layers=2)
+    mod = nets.model_entrypoint("oc20_l1_256_e3_nonlinear")(num_layers=2, otf_graph=False)
     mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
     mod = mod.to(dev).eval()
     pos, batch, Z, tags, ei, off = _slab(2, 24, seed=7)

@@ -156,9 +156,14 @@ def test_oc20_energy_parity():
     yr = ref(Z, tags, pos.double(), batch, edge_index=torch.stack([src, dst]), offsets=off.double())
     data = SimpleNamespace(pos=pos.to(dev), batch=batch.to(dev), atomic_numbers=Z.to(dev), tags=tags.to(dev),
                            edge_index=torch.stack([src, dst]).to(dev), offsets=off.to(dev))
+    mod.otf_graph = False  # explicit edges + Cartesian offsets (this package's extension of the input contract)
     y = mod(data)
     print("oc20 energy rel %.3e (E=%d edges)" % (_rel(y, yr), src.numel()))
     assert _rel(y, yr) < 1e-4
+    with pytest.raises(ValueError):  # periodic model, neither cell_offsets nor offsets
+        mod(SimpleNamespace(pos=pos.to(dev), batch=batch.to(dev), atomic_numbers=Z.to(dev), tags=tags.to(dev),
+                            edge_index=torch.stack([src, dst]).to(dev)))
+    mod.otf_graph = True
     # otf_graph=True / use_pbc=True (the YAML setting): the periodic neighbour search runs on the GPU from data.cell
     from oracle import pbc
     cells = torch.diag(cell)[None].repeat(B, 1, 1)
@@ -170,6 +175,30 @@ def test_oc20_energy_parity():
     y2 = mod(data2)
     print("oc20 otf-graph energy rel %.3e (E=%d edges)" % (_rel(y2, yr2), ei.shape[1]))
     assert _rel(y2, yr2) < 1e-4
+    # otf_graph=True REBUILDS the graph even when the batch carries edges [ref: :267-275]: bogus edges are ignored
+    data2.edge_index = torch.stack([src, dst]).to(dev)[:, :7]
+    assert _rel(mod(data2), yr2) < 1e-4
+    # otf_graph=False: the ocpmodels batch -- edge_index + integer cell_offsets + neighbors + cell [ref: :280-293];
+    # a triclinic cell and a shuffled edge order inside each structure, plus one zero-length edge that must be dropped
+    cells3 = torch.tensor([[[8.0, 0, 0], [1.5, 8.0, 0], [0, 0, 30.0]], [[7.5, 0, 0], [0, 8.5, 0], [0.7, 0, 28.0]]])
+    ei3, coff3, nb3 = pbc.radius_graph_pbc(pos, cells3, [Na] * B, 5.0, 500)
+    perm = torch.cat([torch.randperm(int(n), generator=g) + int(o) for n, o in zip(nb3, torch.cumsum(nb3, 0) - nb3)])
+    ei3, coff3 = ei3[:, perm], coff3[perm]
+    ei3z = torch.cat([torch.tensor([[3], [3]]), ei3], dim=1)
+    coff3z = torch.cat([torch.zeros(1, 3, dtype=coff3.dtype), coff3])
+    nb3z = nb3.clone(); nb3z[0] += 1
+    _, _, offs3 = pbc.get_pbc_distances(pos.double(), ei3, cells3.double(), coff3, nb3)
+    yr3 = ref(Z, tags, pos.double(), batch, edge_index=ei3, offsets=offs3)
+    mod.otf_graph = False
+    data3 = SimpleNamespace(pos=pos.to(dev), batch=batch.to(dev), atomic_numbers=Z.to(dev), tags=tags.to(dev),
+                            cell=cells3.to(dev), natoms=torch.tensor([Na] * B, device=dev), edge_index=ei3z.to(dev),
+                            cell_offsets=coff3z.to(dev), neighbors=nb3z.to(dev))
+    y3 = mod(data3)
+    print("oc20 ocpmodels-batch (edge_index + cell_offsets + neighbors) energy rel %.3e (E=%d)" % (_rel(y3, yr3), ei3.shape[1]))
+    assert _rel(y3, yr3) < 1e-4
+    data3.cell = None
+    with pytest.raises(ValueError):
+        mod(data3)
 
 
 @pytest.mark.parametrize("small", ["SMALL_L2", "SMALL_L3", "SMALL_L3_ATTN_HEAD"])

@@ -78,6 +78,10 @@ HEADS = {
     "aux_l1_feature": dict(use_auxiliary_task=True, irreps_feature="64x0e+32x1e"),
     "aux_linear_message": dict(use_auxiliary_task=True, nonlinear_message=False),
     "l1_feature_energy_only": dict(irreps_feature="64x0e+32x1e"),
+    # E(3) irreps with 1o feature channels: the auxiliary head emits 1x1o [ref: :184-186] (round-2 advisor finding)
+    "aux_e3_1o": dict(use_auxiliary_task=True, irreps_node_embedding="32x0e+16x0o+16x1e+16x1o", irreps_sh="1x0e+1x1o",
+                      irreps_feature="64x0e+16x1e+16x1o", irreps_head="8x0e+4x0o+4x1e+4x1o",
+                      irreps_mlp_mid="64x0e+16x0o+32x1e+16x1o"),
 }
 
 
@@ -117,7 +121,7 @@ def test_oc20_aux_config_full_width():
     torch.manual_seed(0)
     over = dict(irreps_feature="512x0e+256x1e", use_auxiliary_task=True, drop_path_rate=0.05, num_layers=3)
     ref = onets.oc20_l1_256_nonlinear(**over).double().eval()
-    mod = nets.model_entrypoint("oc20_l1_256_nonlinear_aux")(num_layers=3)
+    mod = nets.model_entrypoint("oc20_l1_256_nonlinear_aux")(num_layers=3, otf_graph=False)
     mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
     mod = mod.to(_dev()).eval()
     (er, ar), (e, a) = _run(ref, mod, _slab(2, 40, seed=3))

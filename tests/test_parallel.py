@@ -169,6 +169,88 @@ def test_tail_bucket_is_launched_by_its_last_gradient_whatever_the_order(tmp_pat
     assert r0[True]["launched_after"] < n - 2 <= r0[False]["launched_after"], (r0[True]["launched_after"], r0[False]["launched_after"])
 
 
+class _Branchy(torch.nn.Module):
+    """`c` (in the tail bucket) is skipped when skip_c is set: that rank's hook never completes the tail."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(4)
+        self.a, self.b, self.c = (torch.nn.Linear(6, 6) for _ in range(3))
+        with torch.no_grad():
+            for p in self.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+
+    def forward(self, x, skip_c=False):
+        h = torch.tanh(self.b(torch.tanh(self.a(x))))
+        return (h if skip_c else self.c(h)).sum()
+
+
+def _asym_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from equiformer_amd.parallel import FlatGradAllReduce
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(20 + rank))
+    res = {}
+    # (1) rank 1 does not use a tail parameter: rank 0 launches the tail from its hook, rank 1 only in reduce()
+    model = _Branchy()
+    red = FlatGradAllReduce(model, overlap=0.5)
+    model(x, skip_c=(rank == 1)).backward()
+    res["hook_fired"] = bool(red._tail_done)
+    red.reduce()
+    res["asym"] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    # (2) gradient accumulation: two micro-batches, the first under no_sync()
+    model = _Branchy()
+    red = FlatGradAllReduce(model, overlap=0.5)
+    with red.no_sync():
+        model(x).backward()
+        assert not red._tail_done
+    model(2 * x).backward()
+    assert red._tail_done
+    red.reduce()
+    res["accum"] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    # (3) a second backward() without no_sync() after the tail went out must fail loudly, not corrupt the average
+    model(x).backward()
+    try:
+        model(x).backward()
+        res["raised"] = False
+    except RuntimeError as e:
+        res["raised"] = "no_sync" in str(e)
+    red.reduce()  # leaves both ranks in step: the failed backward stopped inside the hook on both
+    torch.save(res, os.path.join(out, "asym%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_sequence_is_rank_independent_and_accumulation_is_guarded(tmp_path):
+    """Round-2 advisor findings: (medium) a rank whose hook did not fire used to issue ONE whole-buffer all-reduce against
+    the other rank's tail + head pair (mismatched sizes); (low) a second backward() before reduce() was silently wrong."""
+    world = 2
+    mp.spawn(_asym_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "asym0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "asym1.pt"))
+    assert r0["hook_fired"] and not r1["hook_fired"]
+    assert r0["raised"] and r1["raised"]
+    xs = [torch.randn(5, 6, generator=torch.Generator().manual_seed(20 + rank)) for rank in range(world)]
+    ref_asym, ref_acc = {}, {}
+    for rank in range(world):
+        m = _Branchy()
+        m(xs[rank], skip_c=(rank == 1)).backward()
+        for n, p in m.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            ref_asym[n] = ref_asym.get(n, 0) + g / world
+        m = _Branchy()
+        m(xs[rank]).backward()
+        m(2 * xs[rank]).backward()
+        for n, p in m.named_parameters():
+            ref_acc[n] = ref_acc.get(n, 0) + p.grad / world
+    for key, ref in (("asym", ref_asym), ("accum", ref_acc)):
+        for n in ref:
+            assert torch.equal(r0[key][n], r1[key][n]), (key, n)
+            assert torch.allclose(r0[key][n], ref[n], rtol=1e-6, atol=1e-7), (key, n)
+
+
 def test_shard_molecules_partitions_every_molecule_once():
     from equiformer_amd.parallel import shard_molecules
     for n in (0, 1, 7, 128, 1000):

@@ -134,3 +134,30 @@ def test_oc20_full_width_on_the_fly_periodic_graph_oracle_equals_reference(rnets
     assert ei.shape[1] > 100
     eo = o(data.atomic_numbers, data.tags, pos, batch, edge_index=ei, offsets=off)
     assert mrg.rel(eo.detach(), er.detach()) < 1e-10
+
+
+def test_oc20_e3_auxiliary_head_emits_1o_like_the_reference(rnets):
+    """E(3) feature with 1o channels + use_auxiliary_task: the head's output irreps are 1x1o [ref: ..._oc20.py:184-186]
+    (the oracle and the product had 1x1e hard-coded until round 3)."""
+    import make_reference_golden as mrg
+    from nets.graph_attention_transformer_oc20 import GraphAttentionTransformerOC20 as RefOC20
+    from oracle import nets as onets
+    from equiformer_amd.nets.graph_attention_transformer_oc20 import GraphAttentionTransformerOC20 as ProdOC20
+    cfg = dict(irreps_node_embedding="32x0e+16x0o+16x1e+16x1o", num_layers=2, irreps_sh="1x0e+1x1o", max_radius=5.0,
+               number_of_basis=32, fc_neurons=[64, 64], irreps_feature="64x0e+16x1e+16x1o",
+               irreps_head="8x0e+4x0o+4x1e+4x1o", num_heads=4, nonlinear_message=True,
+               irreps_mlp_mid="64x0e+16x0o+32x1e+16x1o", alpha_drop=0.0, use_auxiliary_task=True)
+    torch.manual_seed(1)
+    r = RefOC20(None, None, 1, use_pbc=True, otf_graph=False, **cfg)
+    o = onets.GraphAttentionTransformerOC20(**cfg)
+    mrg.copy_by_name(r, o)
+    torch.manual_seed(1)
+    p = ProdOC20(None, None, 1, use_pbc=True, otf_graph=False, **cfg)
+    assert [(k, tuple(v.shape)) for k, v in p.named_parameters()] == [(k, tuple(v.shape)) for k, v in r.named_parameters()]
+    r, o = mrg.as_double(r), o.double().eval()
+    ins, _ = mrg.load_fixture("oc20_aux_small")
+    t = torch.as_tensor
+    er, ar = r(mrg._oc20_data(ins))
+    eo, ao = o(t(ins["z"]), t(ins["tags"]), t(ins["pos"]).double(), t(ins["batch"]), edge_index=t(ins["edge_index"]),
+               offsets=t(ins["offsets"]).double())
+    assert mrg.rel(eo.detach(), er.detach()) < 1e-10 and mrg.rel(ao.detach(), ar.detach()) < 1e-10
