@@ -78,6 +78,11 @@ SIGNATURES = {
     "eqf_sfc_fwd": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, c_fp, c_fp, _P_IRR, c_fp, c_int, c_int, c_fp],
     "eqf_sfc_bwd_data": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, _P_IRR, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp],
     "eqf_sfc_bwd_weight": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, c_fp, c_int, _PP, c_fp, c_int, c_fp],
+    "eqf_sfcx_packed_numel": [_P_PATHS, _P_IRR, c_int, c_int],
+    "eqf_sfcx_pack": [_PP, c_fp, _P_PATHS, _P_IRR, c_int, c_int, c_fp, c_fp],
+    "eqf_sfcx_fwd": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, c_fp, c_fp, _P_IRR, c_fp, c_int, c_int, c_int, c_fp],
+    "eqf_sfcx_bwd_data": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, _P_IRR, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp],
+    "eqf_sfcx_bwd_weight": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, c_fp, c_int, _PP, c_fp, c_int, c_int, c_fp],
     "eqf_layernorm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, _f, c_fp],
     "eqf_layernorm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, c_fp],
     "eqf_add_layernorm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, _f, c_fp],
@@ -125,6 +130,8 @@ SIGNATURES = {
     "eqf_prof_report": [ctypes.c_char_p, c_int],
 }
 
+RESTYPES = {"eqf_sfcx_packed_numel": ctypes.c_long}  # everything else returns an int status
+
 _lib = None
 
 
@@ -146,7 +153,7 @@ def load():
     lib.eqf_version.argtypes = []
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError -> missing symbol, loud
-        fn.restype = c_int
+        fn.restype = RESTYPES.get(name, c_int)
         fn.argtypes = argtypes
     _lib = lib
     return lib

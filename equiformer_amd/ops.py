@@ -53,6 +53,46 @@ def _want_param_grads():
     return not _input_grads_only.on
 
 
+# ------------------------------------------------------------------------------------------------- matrix-step arithmetic
+# How the matrix steps of the fused SeparableFCTP kernels multiply (csrc/sfcx.hip; C ABI eqf_sfcx_*):
+#   "fp32"    exact-fp32 MFMA (csrc/sfc.hip): bit-equal to an fmaf chain; 1/16 of the bf16 matrix rate, shares the VALU lanes
+#   "split"   fp32 operands split into bf16 planes (activations 2, weights 3), 5 products on the bf16 matrix cores,
+#             fp32 accumulation: fp32-class results (energies 2e-6, gradients 1e-5 vs fp64; tools/split_model_error.py)
+#   "bf16"    plain bf16 operands, fp32 accumulation = torch.autocast(bfloat16), which the reference's drivers switch on by
+#             default (main_qm9.py:117-119,197-201); BASELINE config #2.  Tolerance vs fp32: see tests/test_gpu_sfcx.py
+#   "split6"  3 + 3 planes, 6 products (3e-7): cross-checks
+_MATRIX_MODES = {"fp32": None, "split": 0, "bf16": 1, "split6": 2}
+_matrix_mode = ["split"]
+
+
+def set_matrix_mode(name):
+    """Process-wide arithmetic of the matrix steps; returns the previous mode."""
+    if name not in _MATRIX_MODES:
+        raise ValueError("matrix mode must be one of %s, got %r" % (sorted(_MATRIX_MODES), name))
+    prev = _matrix_mode[0]
+    _matrix_mode[0] = name
+    return prev
+
+
+def get_matrix_mode():
+    return _matrix_mode[0]
+
+
+class matrix_mode:
+    """with ops.matrix_mode("bf16"): ...  -- the autocast-equivalent scope (forward AND the backward that follows must run
+    under the same mode: the packed weight planes saved by the forward are mode-specific, which the backward checks)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = set_matrix_mode(self.name)
+
+    def __exit__(self, *exc):
+        set_matrix_mode(self.prev)
+        return False
+
+
 def _guard_opt(t, dep, what):
     """First-order parameter gradient handed out by a create_graph backward: usable as a value, raises when something
     tries to differentiate through it (second derivatives wrt parameters-of-parameters are not implemented)."""
@@ -1579,6 +1619,20 @@ class SfcSpec:
         self.bias_dim = out_layout.mul_of(0) + self.n2
         used = {l3 for l3, _, _, _ in self.degs}
         self.in_covered = {p["in_off"] for p in table.paths if p["l3"] in used} == set(table.layout_in.offsets)
+        # split-precision kernels (csrc/sfcx.hip): forward / weight gradient up to degree 3, data gradient up to degree 2
+        lmax = max([p["l1"] for p in table.paths] + [l3 for l3, _, _, _ in self.degs])
+        self.x_ok = self.supported
+        self.x_bwd_ok = self.supported and lmax <= 2
+        self._packed_numel = {}
+
+    def packed_numel(self, mode):
+        n = self._packed_numel.get(mode)
+        if n is None:
+            n = lib.load().eqf_sfcx_packed_numel(self.table.c_ref, self.out_layout.c_ref, self.n2, mode)
+            if n <= 0:
+                raise lib.HipLibraryError("eqf_sfcx_packed_numel failed with code %d" % n)
+            self._packed_numel[mode] = n
+        return n
 
 
 def _ptr_array(pairs):
@@ -1605,32 +1659,64 @@ def _guard(t, dep, what):
     return _Guard.apply(t, dep, what) if dep.requires_grad else t
 
 
-def _sfc_fwd(x, coupling, w, weight, bias, weight2, bias2, spec):
+def _sfc_mode(spec):
+    """mode code of the split-precision kernels for this operator, None = exact-fp32 kernels"""
+    m = _MATRIX_MODES[_matrix_mode[0]]
+    return m if (m is not None and spec.x_ok) else None
+
+
+def _sfc_Wl(weight, spec):
+    return _ptr_array((l3, weight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
+
+
+def _sfc_pack(weight, weight2, spec, mode):
+    """bf16 planes of the per-degree weights in MFMA fragment order (forward and data-gradient orientation)"""
+    packed = torch.empty(spec.packed_numel(mode), device=weight.device, dtype=torch.bfloat16)
+    call("eqf_sfcx_pack", _sfc_Wl(weight, spec), _p(weight2), spec.table.c_ref, spec.out_layout.c_ref, spec.n2, mode,
+         ctypes.c_void_p(packed.data_ptr()), _stream())
+    return packed
+
+
+def _sfc_fwd(x, coupling, w, weight, bias, weight2, bias2, spec, mode=None, packed=None):
     E = x.shape[0]
     out1 = torch.empty((E, spec.out_layout.dim), device=x.device, dtype=torch.float32)
     out2 = torch.empty((E, spec.n2), device=x.device, dtype=torch.float32) if spec.n2 else None
-    Wl = _ptr_array((l3, weight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
-    call("eqf_sfc_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(bias), _p(weight2), _p(bias2), _p(out1),
-         spec.out_layout.c_ref, _p(out2), spec.n2, E, _stream())
+    if mode is None:
+        call("eqf_sfc_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, _sfc_Wl(weight, spec), _p(bias), _p(weight2),
+             _p(bias2), _p(out1), spec.out_layout.c_ref, _p(out2), spec.n2, E, _stream())
+    else:
+        if packed is None:
+            packed = _sfc_pack(weight, weight2, spec, mode)
+        call("eqf_sfcx_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, ctypes.c_void_p(packed.data_ptr()), _p(bias),
+             _p(bias2), _p(out1), spec.out_layout.c_ref, _p(out2), spec.n2, E, mode, _stream())
     return out1, out2
 
 
-def _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, want_dM):
+def _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, want_dM, mode=None, packed=None):
     E = x.shape[0]
     dx = (torch.empty_like if spec.in_covered else _zeros_like)(x)
     dw = torch.empty_like(w) if w is not None else None
     dM = _zeros_like(coupling) if want_dM else None
-    Wl = _ptr_array((l3, weight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
-    call("eqf_sfc_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(weight2), _p(d1),
-         spec.out_layout.c_ref, _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, _stream())
+    if mode is None or not spec.x_bwd_ok:
+        call("eqf_sfc_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, _sfc_Wl(weight, spec), _p(weight2), _p(d1),
+             spec.out_layout.c_ref, _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, _stream())
+    else:
+        if packed is None:
+            packed = _sfc_pack(weight, weight2, spec, mode)
+        call("eqf_sfcx_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, ctypes.c_void_p(packed.data_ptr()), _p(d1),
+             spec.out_layout.c_ref, _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, mode, _stream())
     return dx, dM, dw
 
 
-def _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2):
+def _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2, mode=None):
     """dweight (flat) / dweight2, zero-initialised by the caller, are accumulated into."""
-    dWl = _ptr_array((l3, dweight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
-    call("eqf_sfc_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref, _p(d2),
-         spec.n2, dWl, _p(dweight2), x.shape[0], _stream())
+    dWl = _sfc_Wl(dweight, spec)
+    if mode is None:
+        call("eqf_sfc_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref, _p(d2),
+             spec.n2, dWl, _p(dweight2), x.shape[0], _stream())
+    else:
+        call("eqf_sfcx_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref, _p(d2),
+             spec.n2, dWl, _p(dweight2), x.shape[0], mode, _stream())
 
 
 class _SepFctpBwdData(Function):
@@ -1648,7 +1734,8 @@ class _SepFctpBwdData(Function):
         _chk(x, coupling, w, weight, weight2, d1, d2)
         ctx.save_for_backward(x, coupling, w, weight, weight2, d1, d2)
         ctx.spec = spec
-        dx, dM, dw = _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, True)
+        ctx.mode = _sfc_mode(spec)
+        dx, dM, dw = _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, True, ctx.mode)
         if w is None:
             return dx, dM
         return dx, dM, dw
@@ -1657,7 +1744,8 @@ class _SepFctpBwdData(Function):
     @once_differentiable
     def backward(ctx, cx, cM, cw=None):
         x, M, w, weight, weight2, d1, d2 = ctx.saved_tensors
-        spec = ctx.spec
+        spec, mode = ctx.spec, ctx.mode
+        packed = _sfc_pack(weight, weight2, spec, mode) if mode is not None else None
         need = ctx.needs_input_grad  # x, M, w, weight, weight2, d1, d2
         g_x = g_M = g_w = g_W = g_W2 = g_d1 = g_d2 = None
 
@@ -1679,10 +1767,11 @@ class _SepFctpBwdData(Function):
         for (xs, Ms, ws, which) in subs:
             _chk(xs, Ms, ws)
             if need[5] or need[6]:
-                o1, o2 = _sfc_fwd(xs, Ms, ws, weight, None, weight2, None, spec)
+                o1, o2 = _sfc_fwd(xs, Ms, ws, weight, None, weight2, None, spec, mode, packed)
                 g_d1, g_d2 = acc(g_d1, o1), acc(g_d2, o2)
             if need[0] or need[1] or need[2]:
-                dx_, dM_, dw_ = _sfc_bwd_data(xs, Ms, ws, weight, weight2, d1, d2, spec, which != "M" and need[1])
+                dx_, dM_, dw_ = _sfc_bwd_data(xs, Ms, ws, weight, weight2, d1, d2, spec, which != "M" and need[1], mode,
+                                              packed)
                 if which != "x" and need[0]:
                     g_x = acc(g_x, dx_)
                 if which != "M" and need[1]:
@@ -1690,7 +1779,7 @@ class _SepFctpBwdData(Function):
                 if which != "w" and w is not None and need[2]:
                     g_w = acc(g_w, dw_)
             if g_W is not None:
-                _sfc_bwd_weight(xs, Ms, ws, d1, d2, spec, g_W, g_W2)
+                _sfc_bwd_weight(xs, Ms, ws, d1, d2, spec, g_W, g_W2, mode)
         return g_x, g_M, g_w, g_W, g_W2, g_d1, g_d2, None
 
 
@@ -1704,14 +1793,12 @@ class _SepFctp(Function):
         w = _c(w) if w is not None else None
         weight2 = _c(weight2) if weight2 is not None else None
         _chk(x, coupling, w, weight, bias, weight2, bias2)
-        E = x.shape[0]
         assert weight.numel() == spec.weight_numel and (weight2 is None) == (spec.n2 == 0)
         assert weight2 is None or weight2.numel() == spec.weight2_numel
-        out1 = torch.empty((E, spec.out_layout.dim), device=x.device, dtype=torch.float32)
-        out2 = torch.empty((E, spec.n2), device=x.device, dtype=torch.float32) if spec.n2 else None
-        Wl = _ptr_array((l3, weight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
-        call("eqf_sfc_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(bias), _p(weight2), _p(bias2), _p(out1),
-             spec.out_layout.c_ref, _p(out2), spec.n2, E, _stream())
+        ctx.mode = mode = _sfc_mode(spec)
+        # the planes are saved for the data gradient (a raw attribute: the tensor is not part of the autograd graph)
+        ctx.packed = _sfc_pack(weight, weight2, spec, mode) if mode is not None else None
+        out1, out2 = _sfc_fwd(x, coupling, w, weight, bias, weight2, bias2, spec, mode, ctx.packed)
         ctx.save_for_backward(x, coupling, w, weight, weight2)
         ctx.spec = spec
         ctx.has_bias = (bias is not None, bias2 is not None)
@@ -1744,7 +1831,7 @@ class _SepFctp(Function):
                 with torch.no_grad():
                     gW_ = _zeros_like(weight)
                     gW2_ = _zeros_like(weight2) if weight2 is not None else None
-                    _sfc_bwd_weight(x, coupling, w, _c(d1), _c(d2) if spec.n2 else None, spec, gW_, gW2_)
+                    _sfc_bwd_weight(x, coupling, w, _c(d1), _c(d2) if spec.n2 else None, spec, gW_, gW2_, ctx.mode)
                 gW = _guard(gW_, d1, "weight gradient of the fused SeparableFCTP")
                 gW2 = _guard(gW2_, d1, "weight gradient of the fused SeparableFCTP") if gW2_ is not None else None
             if ctx.has_bias[0] and need[4]:
@@ -1764,12 +1851,7 @@ class _SepFctp(Function):
         need = ctx.needs_input_grad
         dx = dM = dw = dweight = dbias = dweight2 = dbias2 = None
         if need[0] or need[1] or (w is not None and need[2]):
-            dx = (torch.empty_like if spec.in_covered else _zeros_like)(x)
-            dw = torch.empty_like(w) if w is not None else None
-            dM = _zeros_like(coupling) if need[1] else None
-            Wl = _ptr_array((l3, weight.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
-            call("eqf_sfc_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, Wl, _p(weight2), _p(d1),
-                 spec.out_layout.c_ref, _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, st)
+            dx, dM, dw = _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, need[1], ctx.mode, ctx.packed)
         want_b = ctx.has_bias[0] and need[4]
         want_b2 = ctx.has_bias[1] and need[6]
         if not _want_param_grads():  # force evaluation
@@ -1782,9 +1864,7 @@ class _SepFctp(Function):
             dweight = flat[:o1]
             dweight2 = flat[o1:o2] if spec.n2 else None
             if need[3] or need[5]:
-                dWl = _ptr_array((l3, flat.data_ptr() + 4 * off) for (l3, _, _, _), off in zip(spec.degs, spec.w_offs))
-                call("eqf_sfc_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref,
-                     _p(d2), spec.n2, dWl, _p(dweight2), E, st)
+                _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2, ctx.mode)
             if want_b:
                 dbias = flat[o2:o3]
                 j = spec.out_layout.seg_index(0)

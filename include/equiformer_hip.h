@@ -257,6 +257,31 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
                        const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2, int n2,
                        float* const* dWl, float* dW2, int E, void* stream);
 
+/* The same fused SeparableFCTP with every matrix step on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32
+ * accumulation).  fp32 operands are split into bf16 planes (value = plane1 + plane2 (+ plane3)); `mode` selects how many:
+ *   0  activations 2 planes, weights 3 planes, 5 plane products (two activation operands: 3)  -- fp32-class results
+ *      (model-level error measured by tools/split_model_error.py: 2e-6 on energies, 1e-5 on gradients vs fp64)
+ *   1  one plane each: plain bf16 operands = the arithmetic of torch.autocast(bfloat16) that the reference's drivers
+ *      enable by default (main_qm9.py:117-119,197-201); BASELINE config #2
+ *   2  3 + 3 planes, 6 products (3e-7), for cross-checks
+ * The weight planes are produced once per weight value by eqf_sfcx_pack into `packed` (eqf_sfcx_packed_numel bf16
+ * elements, 16-byte aligned), in MFMA fragment order for the forward and for the data gradient; the other arguments
+ * are those of eqf_sfc_fwd / _bwd_data / _bwd_weight.  Limits: per-edge tensors < 2^31 elements; the data gradient
+ * supports input / output degrees <= 2 (EQF_E_UNSUPPORTED otherwise: use eqf_sfc_bwd_data).
+ * [ref: as eqf_sfc_fwd; the dtype policy replaces torch.cuda.amp.autocast of engine.py:58-66] */
+long eqf_sfcx_packed_numel(const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int mode);
+int eqf_sfcx_pack(const float* const* Wl, const float* W2, const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps,
+                  int n2, int mode, void* packed, void* stream);
+int eqf_sfcx_fwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths, const void* packed,
+                 const float* bias0, const float* bias2, float* out1, const eqf_irreps* out1_irreps, float* out2, int n2,
+                 int E, int mode, void* stream);
+int eqf_sfcx_bwd_data(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                      const void* packed, const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2, int n2,
+                      float* dx, float* dw, float* d_coupling, int E, int mode, void* stream);
+int eqf_sfcx_bwd_weight(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                        const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2, int n2,
+                        float* const* dWl, float* dW2, int E, int mode, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Row-local feature ops (nodes or edges)
  * ------------------------------------------------------------------------------------------- */

@@ -9,6 +9,8 @@
 #ifndef EQUIFORMER_HIP_DEV_H
 #define EQUIFORMER_HIP_DEV_H
 
+#include "equiformer_hip.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -24,6 +26,11 @@ int eqf_sfc_debug_exp(int mask);
 int eqf_sfc_debug_x6_default(void);
 /* 8 x u64 device counters the sfc kernels add per-phase cycle counts to; NULL disables */
 int eqf_sfc_debug_buffer(void* device_u64x8);
+/* argument tables of the split-precision SeparableFCTP launches (eqf_sfcx_*) as text: kind 0 forward, 1 data gradient,
+ * 2 weight gradient.  Host-only (no GPU needed): tests/test_sfcx_plan.py replays the kernels' lane-level algorithm in
+ * numpy on these tables.  Returns the number of characters written or a negative error. */
+int eqf_sfcx_dev_plan(int kind, const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int E, int mode,
+                      char* buf, int buflen);
 /* gemm kernels: 1 no stores, 2 no MFMA */
 int eqf_gemm_debug_exp(int mask);
 

@@ -1,0 +1,143 @@
+"""Split-precision SeparableFCTP kernels (csrc/sfcx.hip, C ABI eqf_sfcx_*) on the GPU.
+
+Operator level: forward, data gradient (dx, dw, d_coupling) and weight gradient against the exact-fp32 kernels
+(eqf_sfc_*, themselves pinned against the oracle by tests/test_gpu_ops.py / test_gpu_fullsize.py) on the same inputs:
+  mode 2 ("split6", 3 + 3 planes)  -> fp32-class: 5e-6 of the result scale
+  mode 0 ("split", 2 + 3 planes)   -> 1e-4 of the result scale (measured ~1e-5)
+  mode 1 ("bf16")                  -> 3e-2 (plain bf16 operands; the tolerance of BASELINE config #2, stated not assumed:
+                                      the measured value is printed)
+Model level: the QM9 model under ops.matrix_mode("split") meets the north-star bar (1e-4 vs the fp64 oracle) for energies
+and every parameter gradient; under "bf16" the measured errors are printed and bounded.  Bit-reproducibility of the
+forward and the data gradient (no atomics on those paths)."""
+import ctypes
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from equiformer_amd import ops  # noqa: E402
+from equiformer_amd.layout import DtpTable, RowLayout  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-4, 1: 3e-2, 2: 5e-6}
+CASES = {
+    "qm9_sep_act": ("128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "224x0e+64x1e+32x2e", 128, True),
+    "qm9_sep_value": ("128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "128x0e+64x1e+32x2e", 0, False),
+    "oc20_l1": ("256x0e+128x1e", "1x0e+1x1e", "256x0e+128x1e", 0, True),
+    "md17_l3": ("128x0e+64x1e+64x2e+32x3e", "1x0e+1x1e+1x2e+1x3e", "128x0e+64x1e+64x2e+32x3e", 0, True),
+}
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def _problem(case, E, seed=0):
+    irr, sh, out_irr, n2, use_w = CASES[case]
+    dev = _dev()
+    table = DtpTable(irr, sh, irr)
+    lay = RowLayout(out_irr)
+    spec = ops.SfcSpec(table, lay, n2=n2)
+    assert spec.supported and spec.x_ok
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    x, M = r(E, table.layout_in.dim), r(E, table.m_numel)
+    w = r(E, table.weight_numel) if use_w else None
+    weight = r(spec.weight_numel) * 0.1
+    weight2 = r(spec.weight2_numel) * 0.1 if n2 else None
+    bias, bias2 = r(lay.mul_of(0)), (r(n2) if n2 else None)
+    d1, d2 = r(E, lay.dim), (r(E, n2) if n2 else None)
+    return spec, x, M, w, weight, weight2, bias, bias2, d1, d2
+
+
+def _run(spec, x, M, w, weight, weight2, bias, bias2, d1, d2, mode, want_dM=True):
+    o1, o2 = ops._sfc_fwd(x, M, w, weight, bias, weight2, bias2, spec, mode)
+    dx, dM, dw = ops._sfc_bwd_data(x, M, w, weight, weight2, d1, d2, spec, want_dM, mode)
+    gW = torch.zeros_like(weight)
+    gW2 = torch.zeros_like(weight2) if weight2 is not None else None
+    ops._sfc_bwd_weight(x, M, w, d1, d2, spec, gW, gW2, mode)
+    torch.cuda.synchronize()
+    return dict(o1=o1, o2=o2, dx=dx, dM=dM, dw=dw, gW=gW, gW2=gW2)
+
+
+@pytest.mark.parametrize("E", [1000, 37])
+@pytest.mark.parametrize("mode", [2, 0, 1])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_operator_against_exact_fp32_kernels(case, mode, E):
+    args = _problem(case, E)
+    ref = _run(*args, None)
+    got = _run(*args, mode)
+    worst = {}
+    for k, r in ref.items():
+        if r is None:
+            assert got[k] is None
+            continue
+        assert torch.isfinite(got[k]).all(), (case, mode, k)
+        worst[k] = _rel(got[k], r)
+    print("%s mode %d E=%d: %s" % (case, mode, E, {k: "%.1e" % v for k, v in worst.items()}))
+    bad = {k: v for k, v in worst.items() if v > TOL[mode]}
+    assert not bad, (case, mode, bad)
+
+
+def test_bench_size_forward_and_data_gradient_are_bit_reproducible():
+    args = _problem("qm9_sep_act", 25354, seed=3)
+    a = _run(*args, 0, want_dM=False)
+    for _ in range(5):
+        b = _run(*args, 0, want_dM=False)
+        for k in ("o1", "o2", "dx", "dw"):
+            assert torch.equal(a[k], b[k]), k
+    ref = _run(*args, None, want_dM=False)
+    print("E = 25354 split vs fp32 kernels:", {k: "%.1e" % _rel(a[k], ref[k]) for k in ("o1", "o2", "dx", "dw", "gW", "gW2")})
+    for k in ("o1", "o2", "dx", "dw", "gW", "gW2"):
+        assert _rel(a[k], ref[k]) < 1e-4, k
+
+
+def _qm9(mode, B=8):
+    from equiformer_amd import nets
+    from equiformer_amd.synthetic import qm9_like_batch
+    from oracle import nets as onets
+    dev = _dev()
+    torch.manual_seed(0)
+    ref = onets.graph_attention_transformer_nonlinear_l2("5x0e", 5.0).eval()
+    mod = nets.model_entrypoint("graph_attention_transformer_nonlinear_l2")(irreps_in="5x0e", radius=5.0)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(dev).eval()
+    d = qm9_like_batch(B, 18, side=6.5, seed=1)
+    ref = ref.double()
+    yr = ref(None, d["pos"].double(), d["batch"], d["z"])
+    (yr.squeeze() - d["y"].double()).abs().mean().backward()
+    with ops.matrix_mode(mode):
+        y = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
+        (y.squeeze() - d["y"].to(dev)).abs().mean().backward()
+    e_err = _rel(y.detach().cpu(), yr.detach())
+    g_err = max(_rel(p.grad.cpu(), q.grad) for (n, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters())
+                if q.grad is not None and q.grad.abs().max() > 0)
+    return e_err, g_err
+
+
+def test_qm9_model_split_mode_meets_the_north_star_bar():
+    e, g = _qm9("split")
+    print("QM9 model, matrix mode split: energy rel err %.2e, worst parameter-gradient rel err %.2e" % (e, g))
+    assert e < 1e-4 and g < 1e-4
+    e32, g32 = _qm9("fp32")
+    print("QM9 model, matrix mode fp32 : energy rel err %.2e, worst parameter-gradient rel err %.2e" % (e32, g32))
+    assert e32 < 1e-4 and g32 < 1e-4
+
+
+def test_qm9_model_bf16_mode_stated_tolerance():
+    """BASELINE config #2: bf16 operands on the matrix cores (fp32 storage, fp32 accumulation, fp32 layer norm / softmax /
+    radial basis as the reference pins them, nets/layer_norm.py:89).  CPU emulation of the same arithmetic
+    (tools/split_model_error.py): energies 4e-3, gradients 2e-2 -- only the fused SeparableFCTP matrix steps run in bf16
+    here, so the device numbers must be no worse."""
+    e, g = _qm9("bf16")
+    print("QM9 model, matrix mode bf16: energy rel err %.2e, worst parameter-gradient rel err %.2e" % (e, g))
+    assert e < 1e-2 and g < 5e-2

@@ -39,7 +39,7 @@ def test_binding_table_matches_header_prototypes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     text = open(os.path.join(root, "include", "equiformer_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
-    protos = {m.group(1): m.group(2) for m in re.finditer(r"\bint\s+(eqf_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)}
+    protos = {m.group(1): m.group(2) for m in re.finditer(r"\b(?:int|long)\s+(eqf_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)}
     assert len(protos) > 60
     checked = 0
     for name, argtypes in lib.SIGNATURES.items():

@@ -85,6 +85,21 @@ def run(name, irr, sh_irr, out_irr, n2, use_w):
             print("%-10s order %d %-10s E=%d  %8.1f us  %6.1f TFLOP/s  (%.2f GFLOP)"
                   % (name, order, tag, E, us, flops / us / 1e6, flops / 1e9), flush=True)
     _lib.load().eqf_sfc_debug_order(-1)
+    # split-precision kernels (csrc/sfcx.hip): mode 0 = 2 + 3 planes, 1 = plain bf16, 2 = 3 + 3 planes
+    for mode in (0, 1, 2):
+        packed = ops._sfc_pack(weight, weight2, spec, mode)
+        PK = ctypes.c_void_p(packed.data_ptr())
+        fx = lambda: call("eqf_sfcx_fwd", P(x), P(M), P(w), table.c_ref, PK, None, None, P(o1), lay.c_ref, P(o2), n2, E, mode,
+                          st())
+        bx = lambda: call("eqf_sfcx_bwd_data", P(x), P(M), P(w), table.c_ref, PK, P(d1), lay.c_ref, P(d2), n2, P(dx), P(dw),
+                          None, E, mode, st())
+        wx = lambda: call("eqf_sfcx_bwd_weight", P(x), P(M), P(w), table.c_ref, P(d1), lay.c_ref, P(d2), n2, dWl, P(dweight2),
+                          E, mode, st())
+        pk = lambda: ops._sfc_pack(weight, weight2, spec, mode)
+        for tag, fn in (("fwd", fx), ("bwd_data", bx), ("bwd_weight", wx), ("pack", pk)):
+            us = timeit(fn)
+            print("%-10s sfcx mode %d %-10s E=%d  %8.1f us  %6.1f TFLOP/s" % (name, mode, tag, E, us, flops / us / 1e6),
+                  flush=True)
 
 
 run("sep_act", "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "224x0e+64x1e+32x2e", 128, True)
