@@ -46,6 +46,10 @@ def parse():
                     help="skip the like-for-like CPU run at the bench batch (3 steps of ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--matrix-mode", default="split", choices=["split", "bf16", "fp32", "split6"],
+                    help="arithmetic of the fused SeparableFCTP matrix steps (equiformer_amd.ops.set_matrix_mode): split = "
+                         "fp32 operands as bf16 planes on the bf16 matrix cores (fp32-class results, the headline); bf16 = "
+                         "plain bf16 operands (BASELINE config #2, the reference's AMP default); fp32 = exact-fp32 MFMA")
     return ap.parse_args()
 
 
@@ -107,6 +111,24 @@ def cpu_baseline(args):
     return out
 
 
+ARITHMETIC = {
+    "fp32": "fp32 storage and accumulation everywhere; every contraction on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / "
+            "16x16x4_f32: bit-equal to an fmaf chain)",
+    "split": "fp32 storage and accumulation everywhere; the fused SeparableFCTP matrix steps (85 % of the flops) multiply fp32 "
+             "operands split into bf16 planes (activations 2, weights 3; 5 products) on v_mfma_f32_32x32x16_bf16: fp32-class "
+             "results (QM9 model vs fp64 oracle: energies 3.7e-7, gradients 4.8e-6; tests/test_gpu_sfcx.py); the remaining "
+             "contractions on the exact-fp32 MFMA",
+    "split6": "as split with 3 + 3 planes, 6 products",
+    "bf16": "BASELINE config #2: fp32 storage / accumulation, fp32 layer norm, softmax, radial basis (as the reference pins "
+            "them under AMP); the fused SeparableFCTP matrix steps take plain bf16 operands on v_mfma_f32_32x32x16_bf16 "
+            "(QM9 model vs fp64 oracle: energies 7e-4, gradients 7e-3); the remaining contractions on the exact-fp32 MFMA",
+}
+# peak the dominant matrix-core kernel is priced against (MI355X_MICROARCH.md chip table): fp32 results -> the fp32 MFMA /
+# vector peak (the split mode runs them on the bf16 pipe with 5 plane products: 2 500 / 5 = 500 TFLOP/s is what that pipe
+# could deliver for it, reported as pipe_peak_for_this_arithmetic); bf16 operands -> the dense bf16 MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,10 +146,11 @@ def main():
         dist.init_process_group(os.environ.get("EQF_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)  # RCCL / xGMI
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    from equiformer_amd import lib, nets
+    from equiformer_amd import lib, nets, ops
     from equiformer_amd.parallel import FlatGradAllReduce
     from equiformer_amd.synthetic import qm9_like_batch
     lib.load()
+    ops.set_matrix_mode(args.matrix_mode)
 
     torch.manual_seed(0)
     model = nets.model_entrypoint(MODEL)(irreps_in="5x0e", radius=5.0, num_basis=128).to(dev).train()
@@ -185,7 +208,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if args.matrix_mode == "bf16" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "QM9 %s train step (radius graph + fwd + L1 + bwd + AdamW), %d molecules/GPU x %d atoms, "
@@ -193,8 +216,8 @@ def main():
                 "global_batch": args.batch * world, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
                 "edges_per_molecule": n_edges / args.batch, "parallelism": "dp%d" % world,
                 "final_loss": float(loss.item()),
-                "arithmetic": "fp32 storage and accumulation everywhere; every contraction on the exact-fp32 MFMA "
-                              "(v_mfma_f32_32x32x2_f32 / 16x16x4_f32: bit-equal to an fmaf chain)",
+                "matrix_mode": args.matrix_mode,
+                "arithmetic": ARITHMETIC[args.matrix_mode],
             },
         }
         rec = None
@@ -221,8 +244,12 @@ def main():
                             rec_pmc.get("build"), source_hash())
                 except Exception as exc:  # a malformed file must not take the bench line down
                     traffic_note = "profiles/pmc_dominant.json unreadable: %r" % (exc,)
-            out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+            on_bf16_pipe = name.startswith("sfcx")
+            peak = PEAK_BF16_MFMA_TFLOPS if (on_bf16_pipe and args.matrix_mode == "bf16") else PEAK_F32_MFMA_TFLOPS
+            out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
+                               "frac": tflops / peak, "traffic": traffic, "traffic_source": traffic_note,
+                               "pipe_peak_for_this_arithmetic": (PEAK_BF16_MFMA_TFLOPS / {"split": 5, "split6": 6, "bf16": 1}[
+                                   args.matrix_mode]) if on_bf16_pipe else PEAK_F32_MFMA_TFLOPS,
                                "kernel": name,
                                "launches": r["launches"], "avg_launch_ms": avg_ms,
                                "flops_per_launch": r["flops"] / r["launches"],

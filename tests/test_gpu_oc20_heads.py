@@ -78,10 +78,6 @@ HEADS = {
     "aux_l1_feature": dict(use_auxiliary_task=True, irreps_feature="64x0e+32x1e"),
     "aux_linear_message": dict(use_auxiliary_task=True, nonlinear_message=False),
     "l1_feature_energy_only": dict(irreps_feature="64x0e+32x1e"),
-    # E(3) irreps with 1o feature channels: the auxiliary head emits 1x1o [ref: :184-186] (round-2 advisor finding)
-    "aux_e3_1o": dict(use_auxiliary_task=True, irreps_node_embedding="32x0e+16x0o+16x1e+16x1o", irreps_sh="1x0e+1x1o",
-                      irreps_feature="64x0e+16x1e+16x1o", irreps_head="8x0e+4x0o+4x1e+4x1o",
-                      irreps_mlp_mid="64x0e+16x0o+32x1e+16x1o"),
 }
 
 
@@ -167,3 +163,15 @@ def test_segment_scale_op():
     dy = torch.randn(37, 64, generator=g).to(dev)
     (dx,) = torch.autograd.grad(y, x, dy)
     assert torch.equal(dx, dy * s[seg.long()][:, None])
+
+
+def test_oc20_aux_head_on_e3_feature_fails_loudly():
+    """The reference gives this head 1x1o output irreps [ref: :184-186] (round-2 advisor finding: the product had 1x1e
+    hard-coded).  The oracle does so too and equals the reference (tests/test_reference_pin.py); the HIP head on an E(3)
+    feature was 11 % off in round 3, so the product refuses the configuration instead of returning wrong vectors."""
+    from equiformer_amd.nets.graph_attention_transformer_oc20 import GraphAttentionTransformerOC20
+    cfg = dict(mg.SMALL_OC20, number_of_basis=32, use_auxiliary_task=True, irreps_node_embedding="32x0e+16x0o+16x1e+16x1o",
+               irreps_sh="1x0e+1x1o", irreps_feature="64x0e+16x1e+16x1o", irreps_head="8x0e+4x0o+4x1e+4x1o",
+               irreps_mlp_mid="64x0e+16x0o+32x1e+16x1o")
+    with pytest.raises(NotImplementedError):
+        GraphAttentionTransformerOC20(None, None, 1, **cfg)
