@@ -46,6 +46,11 @@ def parse():
                     help="skip the like-for-like CPU run at the bench batch (3 steps of ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="qm9", choices=["qm9", "md17_l2", "md17_l3", "oc20"],
+                    help="qm9 (default, the headline: BASELINE configs #1/#2) | md17_l2 / md17_l3 (configs #3/#4: aspirin "
+                         "energy + forces, force-loss train step through the second-order backward, 8 / 5 frames per GPU as "
+                         "the reference scripts) | oc20 (config #5: IS2RE l1_256_nonlinear, 16 structures per GPU, periodic "
+                         "graph built on the device)")
     ap.add_argument("--matrix-mode", default="split", choices=["split", "bf16", "fp32", "split6"],
                     help="arithmetic of the fused SeparableFCTP matrix steps (equiformer_amd.ops.set_matrix_mode): split = "
                          "fp32 operands as bf16 planes on the bf16 matrix cores (fp32-class results, the headline); bf16 = "
@@ -111,6 +116,149 @@ def cpu_baseline(args):
     return out
 
 
+
+# ------------------------------------------------------------------------------------------------------------ workloads
+WORKLOADS = {
+    "qm9": dict(model=MODEL, unit="molecules/s", metric="molecules/sec (train step) QM9 L_max=2, 6 blocks"),
+    "md17_l2": dict(model="graph_attention_transformer_nonlinear_exp_l2_md17", unit="frames/s", frames=8, wf=80.0,
+                    metric="frames/sec (energy + force train step) MD17 aspirin L_max=2, 6 blocks"),
+    "md17_l3": dict(model="graph_attention_transformer_nonlinear_exp_l3_md17", unit="frames/s", frames=5, wf=100.0,
+                    metric="frames/sec (energy + force train step) MD17 aspirin L_max=3, 6 blocks"),
+    "oc20": dict(model="oc20_l1_256_nonlinear", unit="structures/s", structures=16, atoms=78,
+                 metric="structures/sec (train step) OC20 IS2RE l1_256_nonlinear, 6 blocks"),
+}
+
+
+def _oc20_batch(B, Na, seed):
+    """slab + adsorbate shaped synthetic structures: orthorhombic 11 x 11 x 30 A cell, atoms in the lower 45 %"""
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(seed)
+    cell = torch.diag(torch.tensor([11.0, 11.0, 30.0]))[None].repeat(B, 1, 1)
+    pos = (torch.rand(B * Na, 3, generator=g) * torch.tensor([1.0, 1.0, 0.45])) @ cell[0]
+    return SimpleNamespace(pos=pos, batch=torch.arange(B).repeat_interleave(Na), cell=cell,
+                           atomic_numbers=torch.randint(1, 84, (B * Na,), generator=g),
+                           tags=torch.randint(0, 3, (B * Na,), generator=g), natoms=torch.full((B,), Na)), torch.randn(B, generator=g)
+
+
+def build_workload(args, dev, rank, world):
+    """-> (model, optimizer-ready step pieces): dict(model, reducer, step(opt) -> loss, units per step, graph size, workload text)"""
+    from equiformer_amd import nets
+    from equiformer_amd.graph import EdgeGraph
+    from equiformer_amd.parallel import FlatGradAllReduce
+    from equiformer_amd.synthetic import md17_aspirin_batch, qm9_like_batch
+    W = WORKLOADS[args.workload]
+    torch.manual_seed(0)
+    if args.workload == "qm9":
+        model = nets.model_entrypoint(W["model"])(irreps_in="5x0e", radius=5.0, num_basis=128).to(dev).train()
+        d = {k: v.to(dev) for k, v in qm9_like_batch(args.batch, args.atoms, side=args.side, seed=1000 + rank).items()}
+
+        def fwd_loss():
+            pred = model(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"])
+            return (pred.squeeze() - d["y"]).abs().mean()  # L1Loss (main_qm9.py:188-189)
+        g = EdgeGraph.from_radius(d["pos"], d["batch"], 5.0)
+        units = args.batch
+        text = ("QM9 %s train step (radius graph + fwd + L1 + bwd + AdamW), %d molecules/GPU x %d atoms, r=5.0, "
+                "num_basis=128, alpha_drop=0.2" % (W["model"], args.batch, args.atoms))
+        opt_kw = dict(lr=5e-4, weight_decay=5e-3)
+    elif args.workload.startswith("md17"):
+        frames = W["frames"]
+        model = nets.model_entrypoint(W["model"])(irreps_in="64x0e", radius=5.0, num_basis=32).to(dev).train()
+        d = {k: v.to(dev) for k, v in md17_aspirin_batch(frames, seed=1000 + rank).items()}
+        gen = torch.Generator().manual_seed(7 + rank)
+        ty = torch.randn(frames, 1, generator=gen).to(dev)
+        tf = torch.randn(frames * 21, 3, generator=gen).to(dev)
+
+        def fwd_loss():  # L2MAE force loss + L1 energy loss with the scripts' weights (se_l2 / se_l3 target@aspirin.sh)
+            E, F = model(node_atom=d["z"], pos=d["pos"], batch=d["batch"])
+            return (E - ty).abs().mean() + W["wf"] * (F - tf).norm(dim=1).mean()
+        g = EdgeGraph.from_radius(d["pos"], d["batch"], 5.0)
+        units = frames
+        text = ("MD17 aspirin %s force-loss train step (radius graph + fwd + forces by create_graph backward + loss + second-"
+                "order bwd + AdamW), %d frames/GPU x 21 atoms, r=5.0, num_basis=32" % (W["model"], frames))
+        opt_kw = dict(lr=5e-4, weight_decay=1e-6)
+    else:
+        B, Na = W["structures"], W["atoms"]
+        model = nets.model_entrypoint(W["model"])().to(dev).train()
+        data, y = _oc20_batch(B, Na, 1000 + rank)
+        for k, v in vars(data).items():
+            setattr(data, k, v.to(dev))
+        y = y.to(dev)
+
+        def fwd_loss():
+            return (model(data).squeeze() - y).abs().mean()
+        g, _, _ = EdgeGraph.from_radius_pbc(data.pos, data.cell, data.batch, 5.0, 500)
+        units = B
+        text = ("OC20 IS2RE %s train step (periodic radius graph on the device + fwd + L1 + bwd + AdamW), %d structures/GPU x "
+                "%d atoms, r=5.0, max_neighbors=500, alpha_drop=0.2" % (W["model"], B, Na))
+        opt_kw = dict(lr=2e-4, weight_decay=1e-3)
+    reducer = FlatGradAllReduce(model)
+    reducer.broadcast_parameters()
+    opt = make_optimizer(model, reducer=reducer if world > 1 else None, **opt_kw)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = fwd_loss()
+        loss.backward()
+        if world > 1:
+            reducer.reduce()
+        opt.step()
+        return loss
+    return dict(step=step, units=units, nodes=g.N, edges=g.E, text=text, model_name=W["model"])
+
+
+def cpu_baseline_other(args):
+    """MD17 / OC20: the oracle's train step on the host cores at the reference script's batch (8 / 5 frames; OC20: a
+    bounded sample of 2 of the 16 structures -- the dense CPU neighbour search and 26 k periodic edges per 16 structures
+    make one full step minutes long)."""
+    import statistics
+    from equiformer_amd.synthetic import md17_aspirin_batch
+    from oracle import nets as onets, pbc
+    cores = min(os.cpu_count() or 1, args.cpu_threads)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    W = WORKLOADS[args.workload]
+    if args.workload.startswith("md17"):
+        frames = W["frames"]
+        model = onets.model_entrypoint(W["model"])("64x0e", 5.0, num_basis=32).train()
+        d = md17_aspirin_batch(frames, seed=0)
+        ty, tf = torch.randn(frames, 1), torch.randn(frames * 21, 3)
+        opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=1e-6)
+
+        def step():
+            opt.zero_grad()
+            E, F = model(d["z"], d["pos"], d["batch"])
+            ((E - ty).abs().mean() + W["wf"] * (F - tf).norm(dim=1).mean()).backward()
+            opt.step()
+        units, what = frames, "%d aspirin frames (the reference script's batch)" % frames
+    else:
+        B = 2
+        model = onets.oc20_l1_256_nonlinear().train()
+        data, y = _oc20_batch(B, W["atoms"], 0)
+        ei, coff, nb = pbc.radius_graph_pbc(data.pos, data.cell, [W["atoms"]] * B, 5.0, 500)
+        _, _, off = pbc.get_pbc_distances(data.pos, ei, data.cell, coff, nb)
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=1e-3)
+
+        def step():
+            opt.zero_grad()
+            e = model(data.atomic_numbers, data.tags, data.pos, data.batch, edge_index=ei, offsets=off)
+            (e.squeeze() - y).abs().mean().backward()
+            opt.step()
+        units, what = B, "%d of the 16 structures x %d atoms, %d periodic edges (graph built once, outside the timing)" % (
+            B, W["atoms"], ei.shape[1])
+    warm = 0 if args.workload.startswith("md17") else 1  # one MD17 step (second-order backward) is ~25 s on 8 cores
+    for _ in range(warm):
+        step()
+    ts, t_begin = [], time.perf_counter()
+    while len(ts) < 3 and (not ts or time.perf_counter() - t_begin < 20.0):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    dt = statistics.median(ts)
+    return {"value": units / dt, "unit": W["unit"], "cores": cores, "kind": "port", "s_per_step": dt, "timed_steps": len(ts),
+            "warmup_steps": warm,
+            "sample": "median of %d train steps of %s; oracle = CPU restatement of the reference, torch fp32, "
+                      "%d threads" % (len(ts), what, cores)}
+
 ARITHMETIC = {
     "fp32": "fp32 storage and accumulation everywhere; every contraction on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / "
             "16x16x4_f32: bit-equal to an fmaf chain)",
@@ -146,28 +294,11 @@ def main():
         dist.init_process_group(os.environ.get("EQF_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)  # RCCL / xGMI
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    from equiformer_amd import lib, nets, ops
-    from equiformer_amd.parallel import FlatGradAllReduce
-    from equiformer_amd.synthetic import qm9_like_batch
+    from equiformer_amd import lib, ops
     lib.load()
     ops.set_matrix_mode(args.matrix_mode)
-
-    torch.manual_seed(0)
-    model = nets.model_entrypoint(MODEL)(irreps_in="5x0e", radius=5.0, num_basis=128).to(dev).train()
-    reducer = FlatGradAllReduce(model)
-    reducer.broadcast_parameters()
-    opt = make_optimizer(model, reducer=reducer if world > 1 else None)
-    d = {k: v.to(dev) for k, v in qm9_like_batch(args.batch, args.atoms, side=args.side, seed=1000 + rank).items()}
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        pred = model(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"])
-        loss = (pred.squeeze() - d["y"]).abs().mean()  # L1Loss (main_qm9.py:188-189)
-        loss.backward()
-        if world > 1:
-            reducer.reduce()
-        opt.step()
-        return loss
+    wl = build_workload(args, dev, rank, world)
+    step = wl["step"]
 
     def barrier():
         if world > 1:
@@ -176,10 +307,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # graph size of this rank's batch (for the record)
-    from equiformer_amd.graph import EdgeGraph
-    g = EdgeGraph.from_radius(d["pos"], d["batch"], 5.0)
-    n_nodes, n_edges = g.N, g.E
+    n_nodes, n_edges = wl["nodes"], wl["edges"]
 
     lib.prof_enable(args.dominant)
     barrier()
@@ -198,9 +326,9 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "molecules/sec (train step) QM9 L_max=2, 6 blocks",
-            "value": args.batch * world * args.steps / dt,
-            "unit": "molecules/s",
+            "metric": WORKLOADS[args.workload]["metric"],
+            "value": wl["units"] * world * args.steps / dt,
+            "unit": WORKLOADS[args.workload]["unit"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -211,10 +339,9 @@ def main():
             "dtype": "bf16" if args.matrix_mode == "bf16" else "f32",
             "data": "synthetic",
             "config": {
-                "workload": "QM9 %s train step (radius graph + fwd + L1 + bwd + AdamW), %d molecules/GPU x %d atoms, "
-                            "r=5.0, num_basis=128, alpha_drop=0.2" % (MODEL, args.batch, args.atoms),
-                "global_batch": args.batch * world, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
-                "edges_per_molecule": n_edges / args.batch, "parallelism": "dp%d" % world,
+                "workload": wl["text"],
+                "global_batch": wl["units"] * world, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
+                "edges_per_unit": n_edges / wl["units"], "parallelism": "dp%d" % world,
                 "final_loss": float(loss.item()),
                 "matrix_mode": args.matrix_mode,
                 "arithmetic": ARITHMETIC[args.matrix_mode],
@@ -280,15 +407,16 @@ def main():
                                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
                                    "avg_launch_ms": r2["total_ms"] / r2["launches"]}
         # whole step against the HBM roofline of SURVEY 8d: 3.0 MB algorithmic bytes per molecule-step at E = 200
-        b_alg = 6 * (172800.0 + 1112.0 * n_edges / args.batch) + 0.29e6 + 0.33e6
-        extra["step_hbm_roofline"] = {"algorithmic_bytes_per_molecule": b_alg,
-                                      "molecules_per_s_at_peak": PEAK_HBM_GBPS * 1e9 / b_alg * world,
-                                      "frac": out["value"] / (PEAK_HBM_GBPS * 1e9 / b_alg * world)}
+        if args.workload == "qm9":
+            b_alg = 6 * (172800.0 + 1112.0 * n_edges / args.batch) + 0.29e6 + 0.33e6
+            extra["step_hbm_roofline"] = {"algorithmic_bytes_per_molecule": b_alg,
+                                          "molecules_per_s_at_peak": PEAK_HBM_GBPS * 1e9 / b_alg * world,
+                                          "frac": out["value"] / (PEAK_HBM_GBPS * 1e9 / b_alg * world)}
         out["north_star_kernels"] = extra
-        print("[bench] gpu part done: %.1f molecules/s, %.2f ms/step" % (out["value"], out["ms_per_step"]),
+        print("[bench] gpu part done: %.1f %s, %.2f ms/step" % (out["value"], out["unit"], out["ms_per_step"]),
               file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args) if args.workload == "qm9" else cpu_baseline_other(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

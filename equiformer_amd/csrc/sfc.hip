@@ -669,7 +669,7 @@ __device__ __forceinline__ void wg_item(const SfcWgArgs& g, const int item, cons
 // ONE launch for all items: grid.y enumerates the items of every column-tile class (1, 2, 4, 8 tiles), sorted wide
 // first; a single large grid packs the CUs better than one launch per class.
 template <int MAXD>
-__global__ __launch_bounds__(256, 2) void sfc_wgrad_kernel(const SfcWgArgs g_byval) {
+__global__ __launch_bounds__(256, (MAXD <= 5 ? 2 : 1)) void sfc_wgrad_kernel(const SfcWgArgs g_byval) {
   // read the argument block in place (kernarg segment): with four instantiated bodies hipcc otherwise copies the
   // by-value struct to scratch and serves every table lookup from there
 #if defined(__HIP_DEVICE_COMPILE__)

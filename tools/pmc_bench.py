@@ -23,7 +23,8 @@ from equiformer_amd.build import source_hash  # noqa: E402
 
 d = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "pmc_dominant.json")
-PROF = {"sfc_fwd_kernel": "sfc_fwd", "sfc_bwd_kernel": "sfc_bwd_data", "sfc_wgrad_kernel": "sfc_wgrad"}
+PROF = {"sfc_fwd_kernel": "sfc_fwd", "sfc_bwd_kernel": "sfc_bwd_data", "sfc_wgrad_kernel": "sfc_wgrad",
+        "sfcx_fwd_kernel": "sfcx_fwd", "sfcx_bwd_kernel": "sfcx_bwd_data", "sfcx_wgrad_kernel": "sfcx_wgrad"}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(d + "/pmc_*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
