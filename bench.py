@@ -46,6 +46,8 @@ def parse():
                     help="skip the like-for-like CPU run at the bench batch (3 steps of ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-wgrad", action="store_true",
+                    help="A/B switch: weight gradients of the fused SeparableFCTP on a side stream beside the data gradient")
     ap.add_argument("--workload", default="qm9", choices=["qm9", "md17_l2", "md17_l3", "oc20"],
                     help="qm9 (default, the headline: BASELINE configs #1/#2) | md17_l2 / md17_l3 (configs #3/#4: aspirin "
                          "energy + forces, force-loss train step through the second-order backward, 8 / 5 frames per GPU as "
@@ -297,6 +299,7 @@ def main():
     from equiformer_amd import lib, ops
     lib.load()
     ops.set_matrix_mode(args.matrix_mode)
+    ops._overlap_wgrad[0] = args.overlap_wgrad
     wl = build_workload(args, dev, rank, world)
     step = wl["step"]
 

@@ -1659,6 +1659,20 @@ def _guard(t, dep, what):
     return _Guard.apply(t, dep, what) if dep.requires_grad else t
 
 
+_side_streams = {}
+# weight gradient of the fused SeparableFCTP on a side stream beside its data gradient: measured +1 % on the QM9 step (14.00 vs
+# 14.15 ms, profiles/r03) -- the data-gradient kernel holds the whole register file of its SIMDs, so little co-resides -- and
+# it blurs the per-kernel HIP-event durations bench.py reports.  Off by default.
+_overlap_wgrad = [False]
+
+
+def _side_stream(dev):
+    st = _side_streams.get(dev)
+    if st is None:
+        st = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _sfc_mode(spec):
     """mode code of the split-precision kernels for this operator, None = exact-fp32 kernels"""
     m = _MATRIX_MODES[_matrix_mode[0]]
@@ -1850,20 +1864,34 @@ class _SepFctp(Function):
         _chk(d1, d2)
         need = ctx.needs_input_grad
         dx = dM = dw = dweight = dbias = dweight2 = dbias2 = None
-        if need[0] or need[1] or (w is not None and need[2]):
-            dx, dM, dw = _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, need[1], ctx.mode, ctx.packed)
         want_b = ctx.has_bias[0] and need[4]
         want_b2 = ctx.has_bias[1] and need[6]
-        if not _want_param_grads():  # force evaluation
-            return dx, dM, dw, None, None, None, None, None
-        if need[3] or need[5] or want_b or want_b2:
+        want_w = _want_param_grads() and (need[3] or need[5] or want_b or want_b2)
+        flat = None
+        if want_w:
             n1_0 = spec.out_layout.mul_of(0)
             sizes = [spec.weight_numel, spec.weight2_numel, n1_0 if want_b else 0, spec.n2 if want_b2 else 0]
             flat = _zeros(sum(sizes), device=dev, dtype=torch.float32)  # ONE fill for every accumulated gradient
             o1, o2, o3 = sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]
             dweight = flat[:o1]
             dweight2 = flat[o1:o2] if spec.n2 else None
-            if need[3] or need[5]:
+        # The weight gradient and the data gradient read the same tensors and write disjoint ones: the weight gradient goes
+        # out on a side stream and runs beside the data gradient (both kernels leave most of a SIMD's issue slots idle --
+        # their waves wait on memory > 50 % of the time, profiles/r03 -- so the two overlap instead of queueing).
+        side = _side_stream(dev) if (want_w and (need[3] or need[5]) and _overlap_wgrad[0]) else None
+        if side is not None:
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2, ctx.mode)
+        if need[0] or need[1] or (w is not None and need[2]):
+            dx, dM, dw = _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, need[1], ctx.mode, ctx.packed)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+        if not _want_param_grads():  # force evaluation
+            return dx, dM, dw, None, None, None, None, None
+        if want_w:
+            if side is None and (need[3] or need[5]):
                 _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2, ctx.mode)
             if want_b:
                 dbias = flat[o2:o3]
