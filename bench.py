@@ -109,7 +109,9 @@ def cpu_baseline(args):
         out["batch_%d" % big] = {"value": big / big_dt, "s_per_step": big_dt, "timed_steps": big_n, "warmup_steps": 0}
         out["value"] = big / big_dt
         out["sample"] = ("median of %d train steps of %d molecules x %d atoms (the bench batch; oracle = CPU restatement of "
-                         "the reference, torch fp32, %d threads), %.2f s/step; batch %d: median of %d steps, %.3f s/step"
+                         "the reference, torch fp32, %d threads = min(host cores, --cpu-threads)), %.2f s/step, no separate warm-up (a step "
+                         "takes ~35 s: more would not fit the bench's few-minute budget); batch %d: median of %d steps after 3 "
+                         "warm-up steps, %.3f s/step"
                          % (big_n, big, args.atoms, cores, big_dt, args.cpu_molecules, small_n, small_dt))
     else:
         out["value"] = args.cpu_molecules / small_dt

@@ -384,22 +384,35 @@ __global__ void attn_fwd_half_kernel(const float* __restrict__ logit, const floa
   const int half = lane >> 5, gl = lane & 31;
   const int beg = row_ptr[n], end = row_ptr[n + 1];
   const int H = T.H, D4 = T.D >> 2;
+  const int deg = end - beg;
   const int col4 = (gl < T.G) ? head_col(T, h, gl) >> 2 : -1;
-  float mx = -INFINITY;
-  for (int e = beg + lane; e < end; e += 64) mx = fmaxf(mx, logit[(long)e * H + h]);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* const V = reinterpret_cast<const float4*>(value);
+  // A row is ~11 edges: the kernel is a chain of dependent memory round trips, not a stream.  Two of the three are
+  // taken out of the chain: (1) the value rows of the first four edges depend on row_ptr only and are requested BEFORE
+  // the softmax statistics; inside the loop the next four are requested before the current ones are used; (2) the
+  // head's logits are read ONCE, lane j holding edge beg + j, and handed to the edge loop by lane shuffles (rows longer
+  // than 64 edges re-read memory for the rest).
+  float4 xa = (beg + half < end && col4 >= 0) ? V[(long)(beg + half) * D4 + col4] : z4;
+  float4 xb = (beg + 2 + half < end && col4 >= 0) ? V[(long)(beg + 2 + half) * D4 + col4] : z4;
+  const float lg = lane < deg ? logit[(long)(beg + lane) * H + h] : -INFINITY;
+  float mx = lg;
+  for (int e = beg + 64 + lane; e < end; e += 64) mx = fmaxf(mx, logit[(long)e * H + h]);
   mx = wave_max(mx);
-  float sm = 0.f;
-  for (int e = beg + lane; e < end; e += 64) sm += __expf(logit[(long)e * H + h] - mx);
+  float sm = lane < deg ? __expf(lg - mx) : 0.f;
+  for (int e = beg + 64 + lane; e < end; e += 64) sm += __expf(logit[(long)e * H + h] - mx);
   sm = wave_sum(sm);
   const float inv = 1.f / (sm + 1e-16f);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int e0 = beg; e0 < end; e0 += 4) {
     const int ea = e0 + half, eb = e0 + 2 + half;
     const bool va = ea < end, vb = eb < end;
-    const float la = va ? logit[(long)ea * H + h] : 0.f, lb = vb ? logit[(long)eb * H + h] : 0.f;
-    const float4 xa = (va && col4 >= 0) ? reinterpret_cast<const float4*>(value)[(long)ea * D4 + col4] : z4;
-    const float4 xb = (vb && col4 >= 0) ? reinterpret_cast<const float4*>(value)[(long)eb * D4 + col4] : z4;
+    const float4 xan = (ea + 4 < end && col4 >= 0) ? V[(long)(ea + 4) * D4 + col4] : z4;
+    const float4 xbn = (eb + 4 < end && col4 >= 0) ? V[(long)(eb + 4) * D4 + col4] : z4;
+    const int ia = ea - beg, ib = eb - beg;
+    float la = __shfl(lg, ia & 63), lb = __shfl(lg, ib & 63);
+    if (ia >= 64 && va) la = logit[(long)ea * H + h];
+    if (ib >= 64 && vb) lb = logit[(long)eb * H + h];
     const float aa = va ? __expf(la - mx) * inv : 0.f, ab = vb ? __expf(lb - mx) * inv : 0.f;
     if (gl == 0) {
       if (va) alpha[(long)ea * H + h] = aa;
@@ -409,6 +422,7 @@ __global__ void attn_fwd_half_kernel(const float* __restrict__ logit, const floa
     const float kb = ab * keep_scale(seed, (unsigned long long)eb * H + h, drop_p);
     acc.x = fmaf(ka, xa.x, acc.x), acc.y = fmaf(ka, xa.y, acc.y), acc.z = fmaf(ka, xa.z, acc.z), acc.w = fmaf(ka, xa.w, acc.w);
     acc.x = fmaf(kb, xb.x, acc.x), acc.y = fmaf(kb, xb.y, acc.y), acc.z = fmaf(kb, xb.z, acc.z), acc.w = fmaf(kb, xb.w, acc.w);
+    xa = xan, xb = xbn;
   }
   acc.x += __shfl_xor(acc.x, 32), acc.y += __shfl_xor(acc.y, 32);
   acc.z += __shfl_xor(acc.z, 32), acc.w += __shfl_xor(acc.w, 32);

@@ -29,7 +29,8 @@ struct AdamArgs {
   const float* g;
   float* m;
   float* v;
-  const float* wd;     // per-element weight decay (0 for the no-decay group)
+  const float* wd;     // per-element weight decay (0 for the no-decay group); NEGATIVE = the element's parameter has no
+                       // gradient this step: torch.optim.AdamW skips it entirely (only the EMA follows the weight)
   float* ema;          // may be null
   const float* sumsq;  // may be null (no clipping)
   long n;
@@ -38,6 +39,10 @@ struct AdamArgs {
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float wd, float* ema, const AdamArgs& a,
                                          float clip) {
+  if (wd < 0.f) {
+    if (ema) *ema = a.ema_decay * *ema + (1.f - a.ema_decay) * p;
+    return;
+  }
   g *= clip;
   p *= 1.f - a.lr * wd;                       // decoupled weight decay
   m = a.beta1 * m + (1.f - a.beta1) * g;      // torch: exp_avg.lerp_(grad, 1 - beta1)

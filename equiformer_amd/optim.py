@@ -88,6 +88,8 @@ class FlatAdamW(torch.optim.Optimizer):
             self.flat_ema = self.flat_p.clone()
         self._step = 0
         self._lag = [0] * len(ps)  # steps a parameter missed because it had no gradient (torch keeps a per-parameter count)
+        self._wd_value = [float(wd_of[id(p)]) for p in ps]
+        self._skipped = set()  # parameters whose slice of flat_wd currently holds the kernel's "skip" mark (-1)
 
     @staticmethod
     def _check_params(ps):
@@ -127,21 +129,35 @@ class FlatAdamW(torch.optim.Optimizer):
             if g["lr"] != g0["lr"] or g["betas"] != g0["betas"] or g["eps"] != g0["eps"]:
                 raise ValueError("FlatAdamW: lr / betas / eps must agree across parameter groups")
         # gradients -> flat buffer (already there when the reducer re-pointed .grad at its slices)
-        src, dst, zero, slow = [], [], [], []
+        src, dst, zero, slow, nograd = [], [], [], [], set()
         off = 0
+        offs = []
         for i, (p, v, k) in enumerate(zip(self._params, self._gviews, self.sizes)):
+            offs.append(off)
             if p.grad is None:
                 zero.append(v)
-            elif p.grad.data_ptr() != v.data_ptr():
-                src.append(p.grad)
-                dst.append(v)
-            if p.grad is None or self._lag[i] > 0:
-                slow.append((i, off, k, p.grad is not None))
+                nograd.add(i)
+                self._lag[i] += 1
+            else:
+                if p.grad.data_ptr() != v.data_ptr():
+                    src.append(p.grad)
+                    dst.append(v)
+                if self._lag[i] > 0:
+                    slow.append((i, off, k, True))
             off += k
         # torch.optim.AdamW skips a parameter without a gradient entirely (no decay, no moment decay, its own step
-        # count is not advanced).  The fused kernel updates the whole flat buffer with ONE step count, so the (rare)
-        # parameters that are skipped now, or were skipped before and therefore lag behind the global count, are saved
-        # here and redone below with tensor ops on their slices.
+        # count is not advanced).  The kernel does the same for elements whose weight-decay entry is negative; the
+        # marks are rewritten only when the SET of gradient-less parameters changes (in practice never after the
+        # first step: a model's unused parameters are the same every step), so a step issues no per-parameter copies.
+        # (Before round 3 every such parameter cost eight device-to-device copies per step: 58 per QM9 step.)
+        if nograd != self._skipped:
+            for i in nograd - self._skipped:
+                self.flat_wd[offs[i]:offs[i] + self.sizes[i]].fill_(-1.0)
+            for i in self._skipped - nograd:
+                self.flat_wd[offs[i]:offs[i] + self.sizes[i]].fill_(self._wd_value[i])
+            self._skipped = set(nograd)
+        # Parameters that were skipped BEFORE and have a gradient now lag behind the global step count (their bias
+        # corrections differ): saved here and redone below with tensor ops on their slices.
         saved = [(i, o, k, has, self.flat_p[o:o + k].clone(), self.flat_m[o:o + k].clone(), self.flat_v[o:o + k].clone(),
                   None if self.flat_ema is None else self.flat_ema[o:o + k].clone()) for i, o, k, has in slow]
         if zero:
@@ -169,8 +185,6 @@ class FlatAdamW(torch.optim.Optimizer):
                 sv.mul_(b2).addcmul_(g, g, value=1.0 - b2)
                 denom = (sv.sqrt() / (1.0 - b2 ** t) ** 0.5).add_(eps)
                 sp.addcdiv_(sm, denom, value=-lr / (1.0 - b1 ** t))
-            else:
-                self._lag[i] += 1
             self.flat_p[o:o + k].copy_(sp)
             self.flat_m[o:o + k].copy_(sm)
             self.flat_v[o:o + k].copy_(sv)
@@ -208,6 +222,8 @@ class FlatAdamW(torch.optim.Optimizer):
             for p, k in zip(self._params, self.sizes):
                 self.flat_wd[off:off + k].fill_(float(wd_of[id(p)]))
                 off += k
+            self._wd_value = [float(wd_of[id(p)]) for p in self._params]
+            self._skipped = set()  # the skip marks went with the rewrite; step() puts them back
         self._step = step
         own = {id(p): int(state_dict["state"][i]["step"]) for p, i in zip(order, ids) if i in state_dict["state"]}
         for i, p in enumerate(self._params):

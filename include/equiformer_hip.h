@@ -493,7 +493,8 @@ int eqf_prof_report(char* buf, int buflen);
  * eqf_adamw_step: torch.optim.AdamW update of p[n] from g[n] with state m, v (step = 1-based step count):
  *   g *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) when sumsq != NULL; p *= 1 - lr*wd[i]; m = b1 m + (1-b1) g;
  *   v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); wd[n] = per-element weight decay
- *   (0 for the reference's no-decay names, optim_factory.py:27-42); when ema != NULL also
+ *   (0 for the reference's no-decay names, optim_factory.py:27-42; wd[i] < 0 marks an element whose parameter has
+ *   no gradient this step: p, m, v stay as they are, as torch.optim.AdamW skips such parameters); when ema != NULL also
  *   ema = ema_decay*ema + (1-ema_decay)*p  [ref: timm ModelEmaV2.update called at engine.py:89-90].              */
 int eqf_sumsq(const float* g, long n, float* out, void* stream);
 int eqf_adamw_step(float* p, const float* g, float* m, float* v, const float* wd, float* ema, const float* sumsq,

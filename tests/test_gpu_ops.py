@@ -486,6 +486,29 @@ def test_alpha_and_attention_aggregate(head_irr, H):
     assert _rel(_e3(gout[2], lay), gref[2]) < 1e-5
 
 
+def test_attention_aggregate_long_rows():
+    """Destination rows longer than a wavefront (one dense cluster of 160 atoms: ~159 edges per row): the forward keeps
+    the first 64 logits of a row in registers and re-reads the rest, the value rows are requested one iteration ahead."""
+    from equiformer_amd import ops
+    from equiformer_amd.graph import EdgeGraph
+    from equiformer_amd.layout import RowLayout
+    dev = _dev()
+    gen = torch.Generator().manual_seed(3)
+    pos = torch.rand(160, 3, generator=gen) * 2.0
+    batch = torch.zeros(160, dtype=torch.long)
+    g = EdgeGraph.from_radius(pos.to(dev), batch.to(dev), 5.0)
+    assert g.E == 160 * 159
+    H, oh = 4, oe3.Irreps("32x0e+16x1e+8x2e")
+    lay = RowLayout(repr(onets.sort_irreps_even_first(oh * H)[0].simplify()))
+    dst = g.dst.cpu().long()
+    logit_r = 3.0 * torch.randn(g.E, H, generator=gen, dtype=torch.float64)
+    v = torch.randn(g.E, lay.dim, generator=gen, dtype=torch.float64)
+    alpha_r = onets.segment_softmax(logit_r, dst, g.N).unsqueeze(-1)
+    out_r = onets.heads2vec(onets.scatter_sum(onets.vec2heads(v, oh, H) * alpha_r, dst, g.N), oh)
+    out = ops.attn_aggregate(logit_r.float().to(dev), _cf(v.float().to(dev), lay), g, H, lay, 0.0, 0)
+    assert _rel(_e3(out, lay), out_r) < 1e-5
+
+
 def test_attention_dropout_statistics():
     from equiformer_amd import ops
     from equiformer_amd.graph import EdgeGraph
