@@ -44,12 +44,15 @@ def build(force=False, verbose=True):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "hipcc")
+    # development builds: EQF_EXTRA_FLAGS="-DEQF_DEV_SWITCHES=1" (phase switches / cycle counters inside the sfc and gemm
+    # kernels, tools/sfc_exp.py, tools/gemm_exp.py) or "-DEQF_XTRACE=1" (in-kernel clock samples, tools/sfcx_trace.py)
+    dev = os.environ.get("EQF_EXTRA_FLAGS", "").split()
     objs = []
     procs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + dev + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -24,6 +24,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int g_gemm_exp = 0;
 
+// Development switches (phases of a kernel switched off, per-phase cycle counters) cost scalar instructions inside the hot
+// loops: they are compiled in only with -DEQF_DEV_SWITCHES=1 (EQF_EXTRA_FLAGS="-DEQF_DEV_SWITCHES=1" python -m
+// equiformer_amd.build); in the product build the eqf_*_debug_exp bits that act inside kernels are no-ops.
+#ifndef EQF_DEV_SWITCHES
+#define EQF_DEV_SWITCHES 0
+#endif
+#if EQF_DEV_SWITCHES
+#define GEMM_OFF(g, bit) ((g).exp & (bit))
+#else
+#define GEMM_OFF(g, bit) false
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -324,10 +336,10 @@ __device__ __forceinline__ void gemm_rows_body(const ArgsT& g, const int bx, con
       else
         lbk.issue(g.B, n0, ncnt, k1, g.K, g.vecB);
     }
-    if (!(g.exp & 2)) mma_step<TM, TN, SA, SB>(As, Bs, wm0, wn0, 0, BK, acc);
+    if (!GEMM_OFF(g, 2)) mma_step<TM, TN, SA, SB>(As, Bs, wm0, wn0, 0, BK, acc);
     __syncthreads();
   }
-  if (g.exp & 1) return;
+  if (GEMM_OFF(g, 1)) return;
 
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hi = lane >> 5;

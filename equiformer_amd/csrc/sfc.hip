@@ -31,6 +31,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern __shared__ __attribute__((aligned(16))) float sfc_lds[];  // dynamic LDS of every kernel in this file
 
+// Development switches (phases of a kernel switched off, per-phase cycle counters) cost scalar instructions inside the hot
+// loops: they are compiled in only with -DEQF_DEV_SWITCHES=1 (EQF_EXTRA_FLAGS="-DEQF_DEV_SWITCHES=1" python -m
+// equiformer_amd.build); in the product build the eqf_*_debug_exp bits that act inside kernels are no-ops.
+#ifndef EQF_DEV_SWITCHES
+#define EQF_DEV_SWITCHES 0
+#endif
+#if EQF_DEV_SWITCHES
+#define SFC_OFF(g, bit) ((g).exp & (bit))
+#define SFC_DBG(g) ((g).dbg)
+#else
+#define SFC_OFF(g, bit) false
+#define SFC_DBG(g) ((unsigned long long*)nullptr)
+#endif
+
 namespace {
 
 unsigned long long* g_sfc_dbg = nullptr;  // set by eqf_sfc_debug_buffer (development aid)
@@ -303,7 +317,7 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     // column blocks beyond CT re-read the last valid block (their LDS columns are never used): no guards, no
     // dynamic indexing of bv
     const int wk = s * 32 + (t >> 3);  // row of the weight matrices
-    if (!(g.exp & 8))
+    if (!SFC_OFF(g, 8))
 #pragma unroll
     for (int j = 0; j < CTCAP; ++j) {
       const int c = ncol0 + 32 * (j < CT ? j : CT - 1);  // 32-column block: entirely main or entirely second consumer
@@ -358,7 +372,7 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
   };
   const int bwp = BS0 + (t >> 3) * F_SB + 4 * (t & 7);
   auto commit = [&]() __attribute__((always_inline)) {
-    if (!(g.exp & 2)) switch (s_d1) {
+    if (!SFC_OFF(g, 2)) switch (s_d1) {
       case 1: gen(IC<1>()); break;
       case 3: gen(IC<3>()); break;
       case 5: gen(IC<(MAXD >= 5 ? 5 : 1)>()); break;
@@ -368,11 +382,11 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     for (int j = 0; j < CTCAP; ++j) *reinterpret_cast<f32x4*>(&sfc_lds[bwp + 32 * j]) = bv[j];
   };
 
-  unsigned long long t_mark = g.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long t_mark = SFC_DBG(g) ? __builtin_amdgcn_s_memtime() : 0;
   auto tick = [&](int slot) __attribute__((always_inline)) {
-    if (g.dbg) {
+    if (SFC_DBG(g)) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
-      if (t == 0) atomicAdd(g.dbg + slot, now - t_mark);
+      if (t == 0) atomicAdd(SFC_DBG(g) + slot, now - t_mark);
       t_mark = now;
     }
   };
@@ -408,9 +422,9 @@ __device__ __forceinline__ void f_block(const SfcFwdArgs& g, const int di, const
     tick(1);  // wait for the prefetched inputs + generation + LDS writes
     __syncthreads();
     tick(2);  // barrier
-    if (s + 1 < nslab && !(g.exp & 4)) issue(s + 1);
+    if (s + 1 < nslab && !SFC_OFF(g, 4)) issue(s + 1);
     tick(3);  // issue of the next slab's loads
-    if (!(g.exp & 1)) {
+    if (!SFC_OFF(g, 1)) {
       if constexpr (X6) {
         switch (NT) {
           case 1: f_mma6<D3, 1, FT>(aidx, bidx, acc); break;
@@ -742,11 +756,11 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
   const int el0 = 16 * eh + 4 * kg;    // first of this lane's 4 edges
   const int mt_len = G.mt_len;
 
-  unsigned long long t_mark = g.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long t_mark = SFC_DBG(g) ? __builtin_amdgcn_s_memtime() : 0;
   auto tick = [&](int slot) __attribute__((always_inline)) {
-    if (g.dbg) {
+    if (SFC_DBG(g)) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
-      if (t == 0) atomicAdd(g.dbg + slot, now - t_mark);
+      if (t == 0) atomicAdd(SFC_DBG(g) + slot, now - t_mark);
       t_mark = now;
     }
   };
@@ -860,7 +874,7 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
         // fragments of the first two k blocks (segment lengths are multiples of 32): in flight across the staging
         f32x4 bA = *reinterpret_cast<const f32x4*>(rowA + kc0);
         f32x4 bB = *reinterpret_cast<const f32x4*>(rowA + kc0 + 16);
-        if (!(nchunk == 1 && staged_deg == P.deg) && !((g.exp & 4) && staged_deg >= 0)) {
+        if (!(nchunk == 1 && staged_deg == P.deg) && !(SFC_OFF(g, 4) && staged_deg >= 0)) {
           __syncthreads();  // readers of the previous Dt contents are done
           // stage Dt[k][row] = d_out[e0 + el, m3, kc0 + k],  row = m3*32 + el.  A wave step covers 16 float4 columns x
           // 4 rows; all loads of a group of column blocks are issued before the first LDS write.
@@ -952,8 +966,8 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
           }
           if (kb < kb1) pair(bA, bB, kb);  // segment lengths are multiples of 32: at most one pair is left
         };
-        if (!(g.exp & 1)) seg(0, endA, rowA);
-        if (endA < kcn && !(g.exp & 1)) {
+        if (!SFC_OFF(g, 1)) seg(0, endA, rowA);
+        if (endA < kcn && !SFC_OFF(g, 1)) {
           bA = *reinterpret_cast<const f32x4*>(w2row + kc0 + endA);
           bB = *reinterpret_cast<const f32x4*>(w2row + kc0 + endA + 16);
           seg(endA, kcn, w2row);
@@ -961,7 +975,7 @@ __device__ __forceinline__ void b_block(const SfcBwdArgs& g, const SfcBGroup& G,
       }
       tick(2);  // MFMA loop
       // DTP backward contraction in registers: this lane holds d_mid[m3][edge el0+q][channel 32c + ch]
-      if (!(g.exp & 2))
+      if (!SFC_OFF(g, 2))
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float gw = 0.f;

@@ -5,6 +5,11 @@
  * phase timing of the fused SeparableFCTP and GEMM kernels (tools/sfc_exp.py, tools/bench_sfc.py, tools/sfc_race.py,
  * tools/gemm_exp.py).  They change process-global state, are not thread safe and have no reference counterpart.  Nothing
  * under equiformer_amd/ calls them.
+ *
+ * The switches that act INSIDE kernels (eqf_sfc_debug_exp bits 1, 2, 4, 8; eqf_sfc_debug_buffer; eqf_gemm_debug_exp bits 1,
+ * 2) are compiled in only with -DEQF_DEV_SWITCHES=1 (EQF_EXTRA_FLAGS="-DEQF_DEV_SWITCHES=1" python -m equiformer_amd.build);
+ * in the product build they are accepted and do nothing, so the hot loops carry no test of them.  The in-kernel clock
+ * samples of csrc/sfcx.hip (eqf_sfcx_dev_set_trace, tools/sfcx_trace.py) exist only in a -DEQF_XTRACE=1 build.
  */
 #ifndef EQUIFORMER_HIP_DEV_H
 #define EQUIFORMER_HIP_DEV_H

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Development aid: the radial-MLP GEMM shapes with phases switched off (eqf_gemm_debug_exp: 1 no stores, 2 no MFMA)."""
+"""(needs a development build: EQF_EXTRA_FLAGS="-DEQF_DEV_SWITCHES=1" python -m equiformer_amd.build --force)
+Development aid: the radial-MLP GEMM shapes with phases switched off (eqf_gemm_debug_exp: 1 no stores, 2 no MFMA)."""
 import os
 import sys
 

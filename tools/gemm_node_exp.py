@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Development aid: the node-row grouped GEMMs of a block (2 304 nodes) with phases switched off
+"""(needs a development build: EQF_EXTRA_FLAGS="-DEQF_DEV_SWITCHES=1" python -m equiformer_amd.build --force)
+Development aid: the node-row grouped GEMMs of a block (2 304 nodes) with phases switched off
 (eqf_gemm_debug_exp: 1 no stores, 2 no MFMA, 3 neither)."""
 import os
 import sys

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Development aid: per-phase cycle counters and phase-switch timings of eqf_sfc_bwd_data at the bench size
+"""(needs a development build: EQF_EXTRA_FLAGS="-DEQF_DEV_SWITCHES=1" python -m equiformer_amd.build --force)
+Development aid: per-phase cycle counters and phase-switch timings of eqf_sfc_bwd_data at the bench size
 (mask 128 selected the streamed-weight variant while the LDS-staged-weight experiment of round 2 was in the tree:
 profiles/r02/r02_o_sfc_bwd_wlds_experiment.txt)."""
 import ctypes, os, sys, torch

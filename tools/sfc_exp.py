@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Development aid: time the fused SeparableFCTP kernels with individual phases switched off (eqf_sfc_debug_exp)."""
+"""(needs a development build: EQF_EXTRA_FLAGS="-DEQF_DEV_SWITCHES=1" python -m equiformer_amd.build --force)
+Development aid: time the fused SeparableFCTP kernels with individual phases switched off (eqf_sfc_debug_exp)."""
 import ctypes
 import os
 import sys
