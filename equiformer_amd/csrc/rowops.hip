@@ -139,27 +139,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // latency.  The column-per-thread kernel below stays at 25 us.)
 // d_weight[woff+u] += sum_rows sum_m dy*xhat ; d_bias[boff+u] += sum_rows dy.   One thread per row column,
 // each block reduces CH rows, atomics at the end (columns of the same channel collide only (2l+1) ways).
+constexpr int LN_WGRAD_ROWS = 64, LN_WGRAD_CHUNK = 16;
 __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const float* __restrict__ rstd,
                                                               const float* __restrict__ mean0, float* __restrict__ dw,
-                                                              float* __restrict__ db, int rows, SegTab T, int CH) {
+                                                              float* __restrict__ db, int rows, SegTab T) {
+  constexpr int CH = LN_WGRAD_CHUNK;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= T.D) return;
   int s = 0;
   while (s + 1 < T.nseg && c >= T.off[s + 1]) ++s;
   const int u = (c - T.off[s]) % T.mul[s];
-  const int r0 = blockIdx.y * CH, r1 = min(rows, r0 + CH);
   const bool is0 = T.l[s] == 0;
+  // LN_WGRAD_ROWS rows per thread in chunks of CH: the CH rows of a chunk are requested before the first is used
+  // (compile-time trip count, rows past the end clamped and masked).  The cost of this kernel is its atomics (same-address
+  // fp32 atomics retire at ~0.35 ns each): 64 rows per thread = 37 k of them at 2 304 rows instead of 147 k with 16.
   float aw = 0.f, ab = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const float g = dy[(long)r * T.D + c];
-    float xv = x[(long)r * T.D + c];
-    if (is0) {
-      // mean0 holds the mean of the first 0e segment; other 0e segments (none in practice) recompute
-      xv -= mean0[r];
+  for (int r0 = blockIdx.y * LN_WGRAD_ROWS; r0 < min(rows, (int)(blockIdx.y + 1) * LN_WGRAD_ROWS); r0 += CH) {
+    float gv[CH], xs[CH], rs[CH], m0[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int r = min(r0 + k, rows - 1);
+      gv[k] = dy[(long)r * T.D + c];
+      xs[k] = x[(long)r * T.D + c];
+      rs[k] = rstd[(long)r * T.nseg + s];
+      m0[k] = is0 ? mean0[r] : 0.f;  // mean0 holds the mean of the first 0e segment; other 0e segments (none in practice) recompute
     }
-    aw += g * xv * rstd[(long)r * T.nseg + s];
-    ab += g;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const float g = (r0 + k < rows) ? gv[k] : 0.f;
+      aw += g * (xs[k] - m0[k]) * rs[k];
+      ab += g;
+    }
   }
   atomicAdd(dw + T.woff[s] + u, aw);
   if (T.boff[s] >= 0) atomicAdd(db + T.boff[s] + u, ab);
@@ -621,9 +632,8 @@ int eqf_add_layernorm_bwd(const float* x, const float* weight, const float* dy, 
                      weight, dy, dres, rstd, dx, rows, T);
   EQF_CHECK_LAUNCH();
   if (d_weight && d_bias) {
-    const int CH = 16;  // few rows per thread: the row loop is a chain of dependent loads
-    hipLaunchKernelGGL(layernorm_wgrad_kernel, dim3(eqf_cdiv(T.D, 256), eqf_cdiv(rows, CH)), dim3(256), 0,
-                       (hipStream_t)stream, x, dy, rstd, mean0, d_weight, d_bias, rows, T, CH);
+    hipLaunchKernelGGL(layernorm_wgrad_kernel, dim3(eqf_cdiv(T.D, 256), eqf_cdiv(rows, LN_WGRAD_ROWS)), dim3(256), 0,
+                       (hipStream_t)stream, x, dy, rstd, mean0, d_weight, d_bias, rows, T);
     EQF_CHECK_LAUNCH();
   }
   return 0;
