@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r03_aa; mkdir -p $O; export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r03_af; mkdir -p $O; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_sfcx.py -m gpu -q -x 2>&1 | tail -4 > $O/pytest.txt
 timeout 300 python tools/bench_sfc.py > $O/bench_sfc.txt 2>&1
 cp equiformer_amd/libequiformer_hip.so /tmp/new.so
