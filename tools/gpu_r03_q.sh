@@ -1,5 +1,5 @@
 # in-kernel clock traces (dev build of sfcx.hip with -DEQF_XTRACE=1 installed as equiformer_amd/libequiformer_hip_old.so)
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r03_q2; mkdir -p $O; export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r03_aj; mkdir -p $O; export TMPDIR=/tmp
 cp equiformer_amd/libequiformer_hip.so /tmp/new.so
 cp equiformer_amd/libequiformer_hip_old.so equiformer_amd/libequiformer_hip.so
 timeout 300 python tools/sfcx_trace.py sep_act 0 bwd > $O/trace_bwd_sep_act.txt 2>&1
