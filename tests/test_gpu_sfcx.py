@@ -124,6 +124,38 @@ def _qm9(mode, B=8):
     return e_err, g_err
 
 
+@pytest.mark.parametrize("case", ["qm9_sep_act", "qm9_sep_value"])
+def test_bench_size_properties(case):
+    """Size-independent properties at the BASELINE batch (E = 25 354), split mode: the forward is linear in x (bias aside),
+    the data gradient is linear in d_out, <d_out, F(x)> = <dx, x> (the data gradient is the transpose of the forward in x),
+    and the weight gradient is the transpose of the forward in W: <d_out, F(x; W)> = <gW, W>."""
+    E = 25354
+    spec, x, M, w, weight, weight2, bias, bias2, d1, d2 = _problem(case, E, seed=5)
+    g = torch.Generator().manual_seed(9)
+    x2 = torch.randn(x.shape, generator=g).to(x.device)
+    zb, zb2 = torch.zeros_like(bias), (torch.zeros_like(bias2) if bias2 is not None else None)
+    f = lambda xx: ops._sfc_fwd(xx, M, w, weight, zb, weight2, zb2, spec, 0)  # noqa: E731
+    a, b, ab = f(x), f(x2), f(x + x2)
+    for k in range(2):
+        if a[k] is None:
+            continue
+        assert _rel(a[k] + b[k], ab[k]) < 2e-5, (case, k, _rel(a[k] + b[k], ab[k]))
+    dx1, _, dw1 = ops._sfc_bwd_data(x, M, w, weight, weight2, d1, d2, spec, False, 0)
+    dx2, _, _ = ops._sfc_bwd_data(x, M, w, weight, weight2, 2.0 * d1, None if d2 is None else 2.0 * d2, spec, False, 0)
+    assert _rel(dx2, 2.0 * dx1) < 1e-6  # scaling by two is exact in every plane
+    lhs = (d1.double() * a[0].double()).sum() + (0.0 if d2 is None else (d2.double() * a[1].double()).sum())
+    rhs = (dx1.double() * x.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 2e-5, (case, float(lhs), float(rhs))
+    gW = torch.zeros_like(weight)
+    gW2 = torch.zeros_like(weight2) if weight2 is not None else None
+    ops._sfc_bwd_weight(x, M, w, d1, d2, spec, gW, gW2, 0)
+    rhs_w = (gW.double() * weight.double()).sum() + (0.0 if gW2 is None else (gW2.double() * weight2.double()).sum())
+    assert abs(lhs - rhs_w) / abs(lhs) < 2e-5, (case, float(lhs), float(rhs_w))
+    if w is not None:  # and in the per-edge weights: <d_out, F> = <dw, w>
+        rhs_e = (dw1.double() * w.double()).sum()
+        assert abs(lhs - rhs_e) / abs(lhs) < 2e-5, (case, float(lhs), float(rhs_e))
+
+
 def test_qm9_model_split_mode_meets_the_north_star_bar():
     e, g = _qm9("split")
     print("QM9 model, matrix mode split: energy rel err %.2e, worst parameter-gradient rel err %.2e" % (e, g))
