@@ -10,7 +10,9 @@ maps of v_mfma_f32_32x32x16_bf16, the register epilogues -- and compares the res
 
 and its gradients.  What it pins: the C++ planners and the layout conventions the HIP code transcribes; what it cannot
 pin: the HIP source itself (tests/test_gpu_sfcx.py does that on the device, against the exact-fp32 kernels and the oracle).
-Plane splitting is left out (x = plane1 + plane2 + ... exactly, and the plane products only change rounding)."""
+Plane splitting is left out (x = plane1 + plane2 + ... exactly, and the plane products only change rounding), and so is the
+route an operand takes from memory to its lane since round 3 (row-major tiles through LDS: tests/test_sfcx_tiles.py pins
+those index maps); the replay reads the element each lane ends up with."""
 import ctypes
 import os
 import sys
