@@ -1622,7 +1622,7 @@ class SfcSpec:
         # split-precision kernels (csrc/sfcx.hip): forward / weight gradient up to degree 3, data gradient up to degree 2
         lmax = max([p["l1"] for p in table.paths] + [l3 for l3, _, _, _ in self.degs])
         self.x_ok = self.supported
-        self.x_bwd_ok = self.supported and lmax <= 2
+        self.x_bwd_ok = self.supported and lmax <= 3  # degree-3 slabs: the output degrees are processed in chunks of m3 (csrc/sfcx.hip)
         self._packed_numel = {}
 
     def packed_numel(self, mode):

@@ -434,17 +434,17 @@ def test_weight_gradient_replay_equals_the_definition(case):
         assert _rel(dW[l3], rW[l3]) < 1e-12, l3
 
 
-def test_l3_forward_and_weight_gradient_plans():
-    """MD17 L_max = 3 (config #4): forward and weight gradient are planned (d1, d3 up to 7); the data gradient is not
-    (one-wave register budget) and reports EQF_E_UNSUPPORTED so that callers keep the exact-fp32 kernel for it."""
+def test_l3_plans():
+    """MD17 L_max = 3 (config #4): forward, weight gradient and -- since the output degrees are processed in chunks of m3 --
+    the data gradient are planned (d1, d3 up to 7); the replays equal the definition."""
     irr = "128x0e+64x1e+64x2e+32x3e"
     P = Problem(irr, "1x0e+1x1e+1x2e+1x3e", "128x0e+64x1e+64x2e+32x3e", 0, False, E=40)
     o1, _ = replay_fwd(P)
     r1, _ = P.forward_ref()
     assert _rel(o1, r1) < 1e-12
-    L = lib.load()
-    buf = ctypes.create_string_buffer(1 << 16)
-    rc = L.eqf_sfcx_dev_plan(1, ctypes.cast(P.table.c_ref, ctypes.c_void_p), ctypes.cast(P.lay.c_ref, ctypes.c_void_p), 0, 40, 0,
-                             buf, len(buf))
-    assert rc == -2
-    assert not P.spec.x_bwd_ok and P.spec.x_ok
+    assert P.spec.x_bwd_ok and P.spec.x_ok
+    got = replay_bwd(P)
+    want = P.backward_ref()
+    for a, b in zip(got, want):
+        if a is not None and b is not None:
+            assert _rel(a, b) < 1e-12
