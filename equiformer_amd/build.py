@@ -19,16 +19,41 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 EXTRA_FLAGS = {"sfcx.hip": ["-fno-slp-vectorize"]}
 
 
+def _code_only(text):
+    """C / C++ source without comments and without whitespace (string literals kept verbatim)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        elif c.isspace():
+            i += 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
 def source_hash():
-    """sha256 over the HIP sources + the public header: identifies the build a measurement (profiles/pmc_dominant.json)
-    belongs to."""
+    """sha256 over the CODE of the HIP sources + the public header (comments and whitespace stripped: a build's identity
+    does not change with its documentation): identifies the build a measurement (profiles/pmc_dominant.json) belongs to."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     files.append(os.path.join(HERE, "..", "include", "equiformer_hip.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, "r", encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 
