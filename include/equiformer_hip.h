@@ -266,8 +266,8 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
  *   2  3 + 3 planes, 6 products (3e-7), for cross-checks
  * The weight planes are produced once per weight value by eqf_sfcx_pack into `packed` (eqf_sfcx_packed_numel bf16
  * elements, 16-byte aligned), in MFMA fragment order for the forward and for the data gradient; the other arguments
- * are those of eqf_sfc_fwd / _bwd_data / _bwd_weight.  Limits: per-edge tensors < 2^31 elements; the data gradient
- * supports input / output degrees <= 2 (EQF_E_UNSUPPORTED otherwise: use eqf_sfc_bwd_data).
+ * are those of eqf_sfc_fwd / _bwd_data / _bwd_weight.  Limits: per-edge tensors < 2^31 elements, degrees <= 3, row
+ * strides that are multiples of four floats (EQF_E_UNSUPPORTED otherwise: use the eqf_sfc_* entry point of the same shape).
  * [ref: as eqf_sfc_fwd; the dtype policy replaces torch.cuda.amp.autocast of engine.py:58-66] */
 long eqf_sfcx_packed_numel(const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int mode);
 int eqf_sfcx_pack(const float* const* Wl, const float* W2, const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps,
