@@ -46,6 +46,10 @@ def parse():
                     help="skip the like-for-like CPU run at the bench batch (3 steps of ~15 s)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed regions of K steps each: 1 = only the contract's region; 3 (default) adds two repeats for the spread")
+    ap.add_argument("--no-sub-records", dest="sub_records", action="store_false",
+                    help="skip the compact records of the other BASELINE configurations (bf16 mode, MD17 L2 / L3, OC20)")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="A/B switch: weight gradients of the fused SeparableFCTP on a side stream beside the data gradient")
     ap.add_argument("--workload", default="qm9", choices=["qm9", "md17_l2", "md17_l3", "oc20"],
@@ -266,19 +270,151 @@ def cpu_baseline_other(args):
 ARITHMETIC = {
     "fp32": "fp32 storage and accumulation everywhere; every contraction on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / "
             "16x16x4_f32: bit-equal to an fmaf chain)",
-    "split": "fp32 storage and accumulation everywhere; the fused SeparableFCTP matrix steps (85 % of the flops) multiply fp32 "
-             "operands split into bf16 planes (activations 2, weights 3; 5 products) on v_mfma_f32_32x32x16_bf16: fp32-class "
-             "results (QM9 model vs fp64 oracle: energies 3.7e-7, gradients 4.8e-6; tests/test_gpu_sfcx.py); the remaining "
-             "contractions on the exact-fp32 MFMA",
+    "split": "fp32 storage and accumulation everywhere; the matrix steps of the fused SeparableFCTP (85 % of the flops) and of the "
+             "per-degree / radial linears multiply fp32 operands split into bf16 planes (activations 2, weights 3; 5 products) on "
+             "v_mfma_f32_32x32x16_bf16: fp32-class results (QM9 model vs fp64 oracle: energies / gradients inside 1e-4 with two "
+             "orders of margin; tests/test_gpu_sfcx.py, tests/test_gpu_fullsize.py)",
     "split6": "as split with 3 + 3 planes, 6 products",
     "bf16": "BASELINE config #2: fp32 storage / accumulation, fp32 layer norm, softmax, radial basis (as the reference pins "
-            "them under AMP); the fused SeparableFCTP matrix steps take plain bf16 operands on v_mfma_f32_32x32x16_bf16 "
-            "(QM9 model vs fp64 oracle: energies 7e-4, gradients 7e-3); the remaining contractions on the exact-fp32 MFMA",
+            "them under AMP); every matrix step (fused SeparableFCTP, per-degree linears, radial MLP) takes plain bf16 operands on "
+            "v_mfma_f32_32x32x16_bf16 with fp32 accumulation (tolerances stated in tests/test_gpu_sfcx.py / test_gpu_fullsize.py)",
 }
-# peak the dominant matrix-core kernel is priced against (MI355X_MICROARCH.md chip table): fp32 results -> the fp32 MFMA /
-# vector peak (the split mode runs them on the bf16 pipe with 5 plane products: 2 500 / 5 = 500 TFLOP/s is what that pipe
-# could deliver for it, reported as pipe_peak_for_this_arithmetic); bf16 operands -> the dense bf16 MFMA peak
+# Peaks (MI355X_MICROARCH.md chip table).  A kernel is priced against the pipe it ISSUES on: the split modes run `P` bf16 plane
+# products per algorithmic product on the dense-bf16 matrix pipe, so that pipe can deliver 2 500 / P TFLOP/s of algorithmic work.
 PEAK_BF16_MFMA_TFLOPS = 2500.0
+PRODUCTS = {"split": 5, "split6": 6, "bf16": 1}
+CLOCK_GHZ, N_SIMD = 2.4, 1024
+MFMA_FLOPS_32x32x16 = 2.0 * 32 * 32 * 16   # per v_mfma_f32_32x32x16_bf16
+MFMA_CYCLES_32x32x16 = 32.0                # 8 passes of 4 cycles
+
+
+def kernel_peak(name, mode):
+    """(peak TFLOP/s of the pipe the kernel's matrix instructions issue on, plane products per algorithmic product)"""
+    on_bf16_pipe = name.startswith(("sfcx", "gemmx")) and mode in PRODUCTS
+    if on_bf16_pipe:
+        return PEAK_BF16_MFMA_TFLOPS / PRODUCTS[mode], PRODUCTS[mode]
+    return PEAK_F32_MFMA_TFLOPS, 0
+
+
+def _pmc_record():
+    """profiles/pmc_dominant.json if (and only if) it was measured on the build that is running now"""
+    pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+    if not os.path.exists(pmc):
+        return None, "no PMC measurement for this build (profiles/pmc_dominant.json)"
+    try:
+        from equiformer_amd.build import source_hash
+        rec = json.load(open(pmc))
+        if rec.get("build") == source_hash():
+            return rec, "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE (+ SQ_INSTS_MFMA) over bench.py, build " + rec["build"]
+        return None, "profiles/pmc_dominant.json belongs to build %s, running %s" % (rec.get("build"), source_hash())
+    except Exception as exc:  # a malformed file must not take the bench line down
+        return None, "profiles/pmc_dominant.json unreadable: %r" % (exc,)
+
+
+def roofline_of(prof, dt_s, mode, with_pmc=True):
+    """Roofline object of the matrix-core kernel with the largest total time in `prof` (HIP-event records of a timed region of
+    dt_s seconds).  peak = the pipe the kernel issues on; frac_of_fp32_peak kept as the secondary figure."""
+    rec = None
+    for name, r in prof.items():
+        if r["flops"] > 0 and (rec is None or r["total_ms"] > rec[1]["total_ms"]):
+            rec = (name, r)
+    if rec is None:
+        return None
+    name, r = rec
+    avg_ms = r["total_ms"] / r["launches"]
+    tflops = r["flops"] / r["total_ms"] / 1e9
+    peak, products = kernel_peak(name, mode)
+    alg_bytes = r["bytes"] / r["launches"]
+    out = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+           "peak_is": ("dense bf16 MFMA peak %.0f / %d plane products per algorithmic product" % (PEAK_BF16_MFMA_TFLOPS, products))
+                      if products else "exact-fp32 MFMA peak",
+           "frac_of_fp32_peak": tflops / PEAK_F32_MFMA_TFLOPS,
+           "kernel": name, "launches": r["launches"], "avg_launch_ms": avg_ms,
+           "flops_per_launch": r["flops"] / r["launches"], "algorithmic_bytes_per_launch": alg_bytes,
+           "share_of_step": r["total_ms"] / (1e3 * dt_s)}
+    if products:
+        # matrix-pipe occupancy: MFMA instructions x 32 cycles over 1024 SIMDs at 2.4 GHz, against the launch duration
+        n_mfma = r["flops"] / r["launches"] * products / MFMA_FLOPS_32x32x16
+        out["mfma_busy"] = n_mfma * MFMA_CYCLES_32x32x16 / N_SIMD / (CLOCK_GHZ * 1e9) / (avg_ms * 1e-3)
+        out["mfma_busy_source"] = "analytic: flops_per_launch x %d / 32768 instructions x 32 cycles / 1024 SIMDs / 2.4 GHz" % products
+    out["traffic"], out["traffic_over_algorithmic"] = None, None
+    if with_pmc:
+        pmc, note = _pmc_record()
+        out["traffic_source"] = note
+        if pmc is not None and name in pmc:
+            out["traffic"] = pmc[name].get("hbm_bytes_per_launch")
+            if out["traffic"]:
+                out["traffic_over_algorithmic"] = out["traffic"] / alg_bytes
+            if products and pmc[name].get("mfma_insts_per_launch"):
+                out["mfma_busy"] = (pmc[name]["mfma_insts_per_launch"] * MFMA_CYCLES_32x32x16 / N_SIMD / (CLOCK_GHZ * 1e9)
+                                    / (avg_ms * 1e-3))
+                out["mfma_busy_source"] = "SQ_INSTS_MFMA (PMC pass) x 32 cycles / 1024 SIMDs / 2.4 GHz"
+    return out
+
+
+def measure(args, dev, rank, world, workload, mode, steps, warmup, regions=("sfcx",)):
+    """Build `workload`, run `warmup` untimed steps, then one timed region of EXACTLY `steps` steps per entry of `regions`
+    (barrier + synchronize on both sides, max over ranks).  An entry is the HIP-event filter of that region: a kernel-name
+    substring, "" for every matrix-core kernel, None for no events.  -> (workload dict, [(seconds, event records)], final loss)"""
+    from equiformer_amd import lib, ops
+    prev = ops.set_matrix_mode(mode)
+    a2 = argparse.Namespace(**vars(args))
+    a2.workload = workload
+    wl = build_workload(a2, dev, rank, world)
+    step = wl["step"]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    out = []
+    loss = None
+    for flt in regions:
+        lib.prof_enable(flt)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = lib.prof_report()
+        lib.prof_enable(None)
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        out.append((t.item(), prof))
+    loss = float(loss.item())
+    ops.set_matrix_mode(prev)
+    return wl, out, loss
+
+
+def sub_record(args, dev, workload, mode, steps=10, warmup=3):
+    """Compact record of another BASELINE configuration measured in the same process (one GPU, no CPU leg)."""
+    t0 = time.perf_counter()
+    try:
+        a2 = argparse.Namespace(**vars(args))
+        a2.batch, a2.atoms, a2.side = 128, 18, 6.5
+        wl, regs, loss = measure(a2, dev, 0, 1, workload, mode, steps, warmup, regions=("",))
+        dt, prof = regs[0]
+        rec = {"workload": workload, "matrix_mode": mode, "dtype": "bf16" if mode == "bf16" else "f32",
+               "model": wl["model_name"], "value": wl["units"] * steps / dt, "unit": WORKLOADS[workload]["unit"],
+               "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "units_per_step": wl["units"],
+               "nodes": wl["nodes"], "edges": wl["edges"], "final_loss": loss, "what": wl["text"]}
+        rf = roofline_of(prof, dt, mode, with_pmc=False)
+        if rf:
+            rec["dominant"] = {k: rf[k] for k in ("kernel", "launches", "avg_launch_ms", "achieved", "peak", "frac", "unit",
+                                                  "share_of_step") if k in rf}
+            if "mfma_busy" in rf:
+                rec["dominant"]["mfma_busy"] = rf["mfma_busy"]
+        rec["wall_s"] = time.perf_counter() - t0
+        return rec
+    except Exception as exc:  # a sub-record must not take the headline line down
+        return {"workload": workload, "matrix_mode": mode, "error": repr(exc)[:300]}
+    finally:
+        torch.cuda.empty_cache()
 
 
 def main():
@@ -300,34 +436,16 @@ def main():
 
     from equiformer_amd import lib, ops
     lib.load()
-    ops.set_matrix_mode(args.matrix_mode)
     ops._overlap_wgrad[0] = args.overlap_wgrad
-    wl = build_workload(args, dev, rank, world)
-    step = wl["step"]
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
+    # Region 1 is THE timed region of the contract (W warm-up steps, then exactly K steps): HIP events on the SeparableFCTP
+    # kernels only (the dominant kernel is one of them; `--dominant` overrides).  Regions 2 and 3 repeat the same K steps for the
+    # run-to-run spread: 2 with events on every matrix-core kernel (figures of the other kernels), 3 with no events at all.
+    first = args.dominant if args.dominant else "sfcx"
+    regions = (first, "", None) if args.repeats >= 3 else ((first, "") if args.repeats == 2 else (first,))
+    wl, regs, loss = measure(args, dev, rank, world, args.workload, args.matrix_mode, args.steps, args.warmup, regions)
+    dt, prof = regs[0]
     n_nodes, n_edges = wl["nodes"], wl["edges"]
-
-    lib.prof_enable(args.dominant)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = lib.prof_report()
-    lib.prof_enable(None)
-
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = t.item()
 
     if rank == 0:
         out = {
@@ -347,56 +465,35 @@ def main():
                 "workload": wl["text"],
                 "global_batch": wl["units"] * world, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
                 "edges_per_unit": n_edges / wl["units"], "parallelism": "dp%d" % world,
-                "final_loss": float(loss.item()),
+                "final_loss": loss,
                 "matrix_mode": args.matrix_mode,
                 "arithmetic": ARITHMETIC[args.matrix_mode],
             },
         }
-        rec = None
-        for name, r in prof.items():
-            if rec is None or r["total_ms"] > rec[1]["total_ms"]:
-                rec = (name, r)
-        if rec is not None:
-            name, r = rec
-            avg_ms = r["total_ms"] / r["launches"]
-            tflops = r["flops"] / r["total_ms"] / 1e9
-            # HBM bytes per launch from the PMC passes over this same command (tools/gpu_profile.sh -> tools/pmc_bench.py);
-            # only reported when they were taken on the build that is running now
-            traffic, traffic_note = None, "no PMC measurement for this build (profiles/pmc_dominant.json)"
-            pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
-            if os.path.exists(pmc):
-                try:
-                    from equiformer_amd.build import source_hash
-                    rec_pmc = json.load(open(pmc))
-                    if rec_pmc.get("build") == source_hash():
-                        traffic = rec_pmc.get(name, {}).get("hbm_bytes_per_launch")
-                        traffic_note = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE over bench.py, build " + rec_pmc["build"]
-                    else:
-                        traffic_note = "profiles/pmc_dominant.json belongs to build %s, running %s" % (
-                            rec_pmc.get("build"), source_hash())
-                except Exception as exc:  # a malformed file must not take the bench line down
-                    traffic_note = "profiles/pmc_dominant.json unreadable: %r" % (exc,)
-            on_bf16_pipe = name.startswith("sfcx")
-            peak = PEAK_BF16_MFMA_TFLOPS if (on_bf16_pipe and args.matrix_mode == "bf16") else PEAK_F32_MFMA_TFLOPS
-            out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
-                               "frac": tflops / peak, "traffic": traffic, "traffic_source": traffic_note,
-                               "pipe_peak_for_this_arithmetic": (PEAK_BF16_MFMA_TFLOPS / {"split": 5, "split6": 6, "bf16": 1}[
-                                   args.matrix_mode]) if on_bf16_pipe else PEAK_F32_MFMA_TFLOPS,
-                               "kernel": name,
-                               "launches": r["launches"], "avg_launch_ms": avg_ms,
-                               "flops_per_launch": r["flops"] / r["launches"],
-                               "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
-                               "share_of_step": r["total_ms"] / (1e3 * dt)}
-            # the other matrix-core kernels of the step, same accounting (for the record; not part of the contract)
-            out["roofline"]["others"] = [
-                {"kernel": n2, "launches": r2["launches"], "avg_launch_ms": r2["total_ms"] / r2["launches"],
-                 "achieved": r2["flops"] / r2["total_ms"] / 1e9, "share_of_step": r2["total_ms"] / (1e3 * dt)}
-                for n2, r2 in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]) if n2 != name][:6]
+        vals = [wl["units"] * world * args.steps / d for d, _ in regs]
+        out["spread"] = {"values": vals, "min": min(vals), "max": max(vals),
+                         "note": "the same %d steps timed %d times back to back in this process: [0] = `value` (HIP events on the "
+                                 "SeparableFCTP kernels), [1] events on every matrix-core launch, [2] no events" % (args.steps, len(vals))}
+        rf = roofline_of(prof, dt, args.matrix_mode)
+        allprof = regs[1][1] if len(regs) > 1 else prof
+        if rf is not None:
+            out["roofline"] = rf
+            # the other matrix-core kernels of the step, same accounting (second region; not part of the contract)
+            others = []
+            for n2, r2 in sorted(allprof.items(), key=lambda kv: -kv[1]["total_ms"]):
+                if n2 == rf["kernel"] or r2["flops"] <= 0:
+                    continue
+                pk, _ = kernel_peak(n2, args.matrix_mode)
+                tf = r2["flops"] / r2["total_ms"] / 1e9
+                others.append({"kernel": n2, "launches": r2["launches"], "avg_launch_ms": r2["total_ms"] / r2["launches"],
+                               "achieved": tf, "peak": pk, "frac": tf / pk,
+                               "share_of_step": r2["total_ms"] / (1e3 * regs[1][0] if len(regs) > 1 else 1e3 * dt)})
+            out["roofline"]["others"] = others[:8]
         # the two kernels BASELINE.json's north_star asks to be stated against the gfx950 peaks (not part of the contract
         # line): HBM GB/s of the per-destination softmax + scatter (algorithmic bytes 1 940 E + 1 920 N per call,
         # SURVEY 8d) and MFMA rate of the radial MLP's widest layer (E x 64 -> 960)
         extra = {}
-        sc = prof.get("attn_fwd")
+        sc = allprof.get("attn_fwd")
         if sc:
             byts = 1940.0 * n_edges + 1920.0 * n_nodes
             gbps = byts * sc["launches"] / sc["total_ms"] / 1e6
@@ -404,12 +501,14 @@ def main():
                                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                                 "avg_launch_ms": sc["total_ms"] / sc["launches"], "algorithmic_bytes_per_launch": byts}
         # the widest E-row GEMM with a memory A operand and an [N, K] weight = the radial MLP's last layer
-        rad = [(n2, r2) for n2, r2 in prof.items() if n2.startswith("gemm_rows_") and n2.endswith("_mem_nk")]
+        rad = [(n2, r2) for n2, r2 in allprof.items()
+               if (n2.startswith("gemm_rows_") and n2.endswith("_mem_nk")) or n2.startswith("gemmx_radial")]
         if rad:
             n2, r2 = max(rad, key=lambda kv: kv[1]["flops"] / kv[1]["launches"])
             tf = r2["flops"] / r2["total_ms"] / 1e9
+            pk, _ = kernel_peak(n2, args.matrix_mode)
             extra["radial_mlp"] = {"kernel": n2 + " (radial MLP 64 -> 960)", "bound": "mfma", "achieved": tf,
-                                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+                                   "peak": pk, "unit": "TFLOP/s", "frac": tf / pk, "frac_of_fp32_peak": tf / PEAK_F32_MFMA_TFLOPS,
                                    "avg_launch_ms": r2["total_ms"] / r2["launches"]}
         # whole step against the HBM roofline of SURVEY 8d: 3.0 MB algorithmic bytes per molecule-step at E = 200
         if args.workload == "qm9":
@@ -420,6 +519,16 @@ def main():
         out["north_star_kernels"] = extra
         print("[bench] gpu part done: %.1f %s, %.2f ms/step" % (out["value"], out["unit"], out["ms_per_step"]),
               file=sys.stderr, flush=True)
+        # the other BASELINE configurations, measured in this same run (one GPU; the headline workload only)
+        if world == 1 and args.sub_records and args.workload == "qm9" and args.matrix_mode == "split":
+            del wl, regs
+            torch.cuda.empty_cache()
+            subs = []
+            for wname, mode in (("qm9", "bf16"), ("md17_l2", "split"), ("md17_l3", "split"), ("oc20", "split")):
+                subs.append(sub_record(args, dev, wname, mode))
+                print("[bench] sub-record %s/%s: %s" % (wname, mode, {k: subs[-1].get(k) for k in ("value", "ms_per_step", "error")}),
+                      file=sys.stderr, flush=True)
+            out["configs"] = subs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args) if args.workload == "qm9" else cpu_baseline_other(args)
         print(json.dumps(out), flush=True)

@@ -13,7 +13,7 @@ timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "py
 tail -8 $OUT/pytest.log
 timeout 300 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/prof.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub-records --repeats 1 > $OUT/bench_prof.json 2> $OUT/prof.err
 DB=$(find $OUT/prof -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocpd_stats.py $DB --csv $OUT/kernel_stats.csv --top 70 > $OUT/kernel_stats.txt
 find $OUT/prof -name '*.db' -delete

@@ -3,6 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE -d <dir>/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
     rocprofv3 --pmc WRITE_SIZE -d <dir>/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc SQ_INSTS_MFMA -d <dir>/pmc_mfma -- python bench.py ...   (optional: matrix instructions per launch -> mfma_busy)
     python tools/pmc_bench.py <dir> [profiles/pmc_dominant.json]
 
 Units / corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies
@@ -41,6 +42,9 @@ for name, c in vals.items():
     fetch = 2 * 1024 * sum(f) / len(f)
     write = 1024 * sum(w) / len(w)
     res[name] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "launches_seen": len(f)}
+    m = c.get("SQ_INSTS_MFMA", [])
+    if m:
+        res[name]["mfma_insts_per_launch"] = sum(m) / len(m)
     print("%-14s %.1f MB / launch (fetch %.1f + write %.1f, %d launches)" % (name, (fetch + write) / 1e6, fetch / 1e6,
                                                                           write / 1e6, len(f)))
 json.dump(res, open(out, "w"), indent=1)
