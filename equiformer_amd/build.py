@@ -20,11 +20,12 @@ EXTRA_FLAGS = {"sfcx.hip": ["-fno-slp-vectorize"]}
 
 
 def _code_only(text):
-    """C / C++ source without comments and without whitespace (string literals kept verbatim)."""
+    """C / C++ source without comments, runs of whitespace collapsed to one space (string / character literals kept verbatim;
+    a ' that follows an alphanumeric character is a C++14 digit separator, not a literal)."""
     out, i, n = [], 0, len(text)
     while i < n:
         c = text[i]
-        if c == '"' or c == "'":
+        if c == '"' or (c == "'" and not (i > 0 and (text[i - 1].isalnum() or text[i - 1] == "_"))):
             j = i + 1
             while j < n and text[j] != c:
                 j += 2 if text[j] == "\\" else 1
@@ -36,12 +37,16 @@ def _code_only(text):
         elif text.startswith("/*", i):
             j = text.find("*/", i + 2)
             i = n if j < 0 else j + 2
+            if out and out[-1] != " ":
+                out.append(" ")
         elif c.isspace():
+            if out and out[-1] != " ":
+                out.append(" ")
             i += 1
         else:
             out.append(c)
             i += 1
-    return "".join(out)
+    return "".join(out).strip()
 
 
 def source_hash():

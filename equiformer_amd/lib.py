@@ -79,6 +79,7 @@ SIGNATURES = {
     "eqf_sfc_bwd_data": [c_fp, c_fp, c_fp, _P_PATHS, _PP, c_fp, c_fp, _P_IRR, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp],
     "eqf_sfc_bwd_weight": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, c_fp, c_int, _PP, c_fp, c_int, c_fp],
     "eqf_sfcx_packed_numel": [_P_PATHS, _P_IRR, c_int, c_int],
+    "eqf_sfcx_supported": [_P_PATHS, _P_IRR, c_int, c_int],
     "eqf_sfcx_pack": [_PP, c_fp, _P_PATHS, _P_IRR, c_int, c_int, c_fp, c_fp],
     "eqf_sfcx_fwd": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, c_fp, c_fp, _P_IRR, c_fp, c_int, c_int, c_int, c_fp],
     "eqf_sfcx_bwd_data": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, _P_IRR, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp],

@@ -79,8 +79,9 @@ def get_matrix_mode():
 
 
 class matrix_mode:
-    """with ops.matrix_mode("bf16"): ...  -- the autocast-equivalent scope (forward AND the backward that follows must run
-    under the same mode: the packed weight planes saved by the forward are mode-specific, which the backward checks)."""
+    """with ops.matrix_mode("bf16"): ...  -- the autocast-equivalent scope.  Every operator records the mode of its FORWARD
+    and its gradients (first and second order) run in that recorded mode whatever the global is when backward executes, as
+    autocast's backward does; the packed weight planes saved by the forward are those of the recorded mode."""
 
     def __init__(self, name):
         self.name = name
@@ -1619,11 +1620,27 @@ class SfcSpec:
         self.bias_dim = out_layout.mul_of(0) + self.n2
         used = {l3 for l3, _, _, _ in self.degs}
         self.in_covered = {p["in_off"] for p in table.paths if p["l3"] in used} == set(table.layout_in.offsets)
-        # split-precision kernels (csrc/sfcx.hip): forward / weight gradient up to degree 3, data gradient up to degree 2
-        lmax = max([p["l1"] for p in table.paths] + [l3 for l3, _, _, _ in self.degs])
-        self.x_ok = self.supported
-        self.x_bwd_ok = self.supported and lmax <= 3  # degree-3 slabs: the output degrees are processed in chunks of m3 (csrc/sfcx.hip)
+        # split-precision kernels (csrc/sfcx.hip): each of the three launches has its own table limits (input slabs, work
+        # items, LDS); the planners themselves are asked once per mode (eqf_sfcx_supported, host only) and a launch they
+        # reject is served by the exact-fp32 kernel of the same shape
+        self._x_mask = {}
         self._packed_numel = {}
+
+    def x_mask(self, mode):
+        """bit 0 forward, bit 1 data gradient, bit 2 weight gradient of csrc/sfcx.hip can serve this operator in `mode`"""
+        m = self._x_mask.get(mode)
+        if m is None:
+            m = 0
+            if self.supported:
+                m = lib.load().eqf_sfcx_supported(self.table.c_ref, self.out_layout.c_ref, self.n2, mode)
+                if m < 0:
+                    raise lib.HipLibraryError("eqf_sfcx_supported failed with code %d" % m)
+            self._x_mask[mode] = m
+        return m
+
+    @property
+    def x_ok(self):
+        return self.supported and self.x_mask(0) != 0
 
     def packed_numel(self, mode):
         n = self._packed_numel.get(mode)
@@ -1676,7 +1693,7 @@ def _side_stream(dev):
 def _sfc_mode(spec):
     """mode code of the split-precision kernels for this operator, None = exact-fp32 kernels"""
     m = _MATRIX_MODES[_matrix_mode[0]]
-    return m if (m is not None and spec.x_ok) else None
+    return m if (m is not None and spec.supported and spec.x_mask(m) != 0) else None
 
 
 def _sfc_Wl(weight, spec):
@@ -1695,7 +1712,7 @@ def _sfc_fwd(x, coupling, w, weight, bias, weight2, bias2, spec, mode=None, pack
     E = x.shape[0]
     out1 = torch.empty((E, spec.out_layout.dim), device=x.device, dtype=torch.float32)
     out2 = torch.empty((E, spec.n2), device=x.device, dtype=torch.float32) if spec.n2 else None
-    if mode is None:
+    if mode is None or not (spec.x_mask(mode) & 1):
         call("eqf_sfc_fwd", _p(x), _p(coupling), _p(w), spec.table.c_ref, _sfc_Wl(weight, spec), _p(bias), _p(weight2),
              _p(bias2), _p(out1), spec.out_layout.c_ref, _p(out2), spec.n2, E, _stream())
     else:
@@ -1711,7 +1728,7 @@ def _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, want_dM, mode=N
     dx = (torch.empty_like if spec.in_covered else _zeros_like)(x)
     dw = torch.empty_like(w) if w is not None else None
     dM = _zeros_like(coupling) if want_dM else None
-    if mode is None or not spec.x_bwd_ok:
+    if mode is None or not (spec.x_mask(mode) & 2):
         call("eqf_sfc_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, _sfc_Wl(weight, spec), _p(weight2), _p(d1),
              spec.out_layout.c_ref, _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, _stream())
     else:
@@ -1725,7 +1742,7 @@ def _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, want_dM, mode=N
 def _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2, mode=None):
     """dweight (flat) / dweight2, zero-initialised by the caller, are accumulated into."""
     dWl = _sfc_Wl(dweight, spec)
-    if mode is None:
+    if mode is None or not (spec.x_mask(mode) & 4):
         call("eqf_sfc_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref, _p(d2),
              spec.n2, dWl, _p(dweight2), x.shape[0], _stream())
     else:
@@ -1740,7 +1757,7 @@ class _SepFctpBwdData(Function):
     first-order kernels (forward, data-gradient, weight-gradient) evaluated with one argument substituted."""
 
     @staticmethod
-    def forward(ctx, x, coupling, w, weight, weight2, d1, d2, spec):
+    def forward(ctx, x, coupling, w, weight, weight2, d1, d2, spec, mode):
         x, coupling, weight, d1 = _c(x), _c(coupling), _c(weight), _c(d1)
         w = _c(w) if w is not None else None
         weight2 = _c(weight2) if weight2 is not None else None
@@ -1748,7 +1765,8 @@ class _SepFctpBwdData(Function):
         _chk(x, coupling, w, weight, weight2, d1, d2)
         ctx.save_for_backward(x, coupling, w, weight, weight2, d1, d2)
         ctx.spec = spec
-        ctx.mode = _sfc_mode(spec)
+        # the arithmetic of the forward this is the gradient of (passed in by _SepFctp.backward), not the global of the moment
+        ctx.mode = mode
         dx, dM, dw = _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, True, ctx.mode)
         if w is None:
             return dx, dM
@@ -1794,7 +1812,7 @@ class _SepFctpBwdData(Function):
                     g_w = acc(g_w, dw_)
             if g_W is not None:
                 _sfc_bwd_weight(xs, Ms, ws, d1, d2, spec, g_W, g_W2, mode)
-        return g_x, g_M, g_w, g_W, g_W2, g_d1, g_d2, None
+        return g_x, g_M, g_w, g_W, g_W2, g_d1, g_d2, None, None
 
 
 class _SepFctp(Function):
@@ -1810,7 +1828,9 @@ class _SepFctp(Function):
         assert weight.numel() == spec.weight_numel and (weight2 is None) == (spec.n2 == 0)
         assert weight2 is None or weight2.numel() == spec.weight2_numel
         ctx.mode = mode = _sfc_mode(spec)
-        # the planes are saved for the data gradient (a raw attribute: the tensor is not part of the autograd graph)
+        # the planes are saved for the data gradient (a raw attribute: the tensor is not part of the autograd graph; like
+        # any saved tensor they describe the weights AT FORWARD TIME -- an in-place weight update between forward and backward,
+        # which FlatAdamW's raw-pointer writes would not even trip autograd's version check on, is not supported)
         ctx.packed = _sfc_pack(weight, weight2, spec, mode) if mode is not None else None
         out1, out2 = _sfc_fwd(x, coupling, w, weight, bias, weight2, bias2, spec, mode, ctx.packed)
         ctx.save_for_backward(x, coupling, w, weight, weight2)
@@ -1833,7 +1853,7 @@ class _SepFctp(Function):
                 d1 = _zeros((E, spec.out_layout.dim), device=dev, dtype=torch.float32)
             if spec.n2 and d2 is None:
                 d2 = _zeros((E, spec.n2), device=dev, dtype=torch.float32)
-            outs = _SepFctpBwdData.apply(x, coupling, w, weight, weight2, d1, d2 if spec.n2 else None, spec)
+            outs = _SepFctpBwdData.apply(x, coupling, w, weight, weight2, d1, d2 if spec.n2 else None, spec, ctx.mode)
             dx, dM = outs[0], outs[1]
             dw = outs[2] if w is not None else None
             # needs_input_grad is static (the parameters always "need" a gradient), so the weight / bias gradients

@@ -30,7 +30,11 @@ class FlatGradAllReduce:
     overlap: fraction of the gradient bytes (counted from the END of the forward order) that is all-reduced from a
     hook during backward; 0 disables the hook (one collective in `reduce()`)."""
 
-    def __init__(self, module, process_group=None, overlap=0.5):
+    def __init__(self, module, process_group=None, overlap=0.5, always_reduce=False):
+        # always_reduce: issue the collectives even in a one-rank group (they are the identity there).  Used to exercise the
+        # RCCL path -- ReduceOp.AVG, the asynchronous tail launched from the backward hook -- on a single-GPU box
+        # (tests/test_gpu_parallel.py::test_one_rank_rccl_flat_allreduce); a real one-rank run has no reason to set it.
+        self._always = bool(always_reduce)
         params = [p for p in module.parameters() if p.requires_grad]
         # Layout = forward order, except that parameters whose gradient is only complete at the END of backward although
         # they belong to late layers are moved to the front (the head bucket): a model says which ones through
@@ -69,9 +73,15 @@ class FlatGradAllReduce:
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def _active(self):
+        """collectives are issued: more than one rank, or a one-rank group with always_reduce"""
+        if self.world_size() > 1:
+            return True
+        return self._always and dist.is_available() and dist.is_initialized()
+
     def broadcast_parameters(self, src=0):
         """Replicas start identical (what DDP's constructor does)."""
-        if self.world_size() == 1:
+        if not self._active():
             return
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.group)
@@ -108,7 +118,7 @@ class FlatGradAllReduce:
 
     def _on_tail_grad(self, param):
         """Runs inside backward each time the gradient of a tail-bucket parameter has been accumulated."""
-        if self.world_size() == 1 or self._accumulate:
+        if not self._active() or self._accumulate:
             return
         if self._tail_done:
             # the tail collective of this step is already in flight: a second backward() would accumulate into gradients
@@ -131,13 +141,14 @@ class FlatGradAllReduce:
         launched now -- a rank that fell back to ONE collective over the whole buffer would pair its collective with
         another rank's tail collective (mismatched sizes: hang or corruption)."""
         ws = self.world_size()
+        active = self._active()
         split = self.split < len(self.params)
         if not self._tail_done:
             self._pack(self.split, len(self.params))
-            if ws > 1 and split:
+            if active and split:
                 self._pending = self._all_reduce(self.flat[self.offsets[self.split]:], async_op=True)
         self._pack(0, self.split)
-        if ws > 1:
+        if active:
             head = self.flat[:self.offsets[self.split]] if split else self.flat
             _, need_div_head = self._all_reduce(head, async_op=False)
             if need_div_head:

@@ -270,6 +270,9 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
  * strides that are multiples of four floats (EQF_E_UNSUPPORTED otherwise: use the eqf_sfc_* entry point of the same shape).
  * [ref: as eqf_sfc_fwd; the dtype policy replaces torch.cuda.amp.autocast of engine.py:58-66] */
 long eqf_sfcx_packed_numel(const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int mode);
+/* host only, no launch: bit mask of the split-precision launches that can serve this operator (1 forward, 2 data gradient,
+ * 4 weight gradient; the planners' own verdict on their table limits) -- use the eqf_sfc_* entry point for a cleared bit */
+int eqf_sfcx_supported(const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int mode);
 int eqf_sfcx_pack(const float* const* Wl, const float* W2, const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps,
                   int n2, int mode, void* packed, void* stream);
 int eqf_sfcx_fwd(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths, const void* packed,

@@ -98,6 +98,66 @@ def test_two_rank_hip_model_flat_allreduce(tmp_path):
     assert err < 2e-5, err
 
 
+def _rccl_worker(rank, world, port, out):
+    """ONE rank, backend "nccl" (= RCCL on ROCm) on cuda:0: the collectives are the identity, but they are real RCCL calls --
+    ReduceOp.AVG, the asynchronous tail launched from the backward hook, broadcast, barrier."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from equiformer_amd.optim import FlatAdamW, add_weight_decay
+    from equiformer_amd.parallel import FlatGradAllReduce
+    from equiformer_amd.synthetic import qm9_like_batch
+    res = {"backend": dist.get_backend()}
+    model = _model(dev)
+    red = FlatGradAllReduce(model, always_reduce=True)
+    red.broadcast_parameters()
+    # the AVG branch on its own
+    buf = torch.arange(1000, dtype=torch.float32, device=dev) * 0.5
+    work, need_div = red._all_reduce(buf, async_op=True)
+    work.wait()
+    torch.cuda.synchronize()
+    res["avg_identity"] = bool(torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float32) * 0.5)) and not need_div
+    opt = FlatAdamW(add_weight_decay(model, 5e-3, model.no_weight_decay()), lr=1e-3, reducer=red)
+    d = qm9_like_batch(4, 10, side=5.0, seed=5)
+    opt.zero_grad(set_to_none=True)
+    _loss(model, d, range(4), dev).backward()
+    res["overlapped"] = bool(red._tail_done)      # the tail collective was launched from the hook, inside backward
+    res["pending_is_work"] = red._pending is not None and hasattr(red._pending[0], "wait")
+    res["flat"] = red.reduce().clone().cpu()
+    opt.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.save(res, os.path.join(out, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_flat_allreduce(tmp_path):
+    """RCCL evidence that fits one GPU (the test tier's boxes have one): FlatGradAllReduce's "nccl" branch -- ReduceOp.AVG inside
+    the collective, asynchronous tail from the backward hook, head in reduce() -- runs in a one-rank RCCL group and leaves the
+    gradient equal to the single-process one.  [ref: init_process_group('nccl') utils.py:46-69, DDP main_qm9.py:178-179]"""
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(tmp_path, "rccl.pt"))
+    assert r["backend"] == "nccl"
+    assert r["avg_identity"], "ReduceOp.AVG over one rank must be the identity and need no division"
+    assert r["overlapped"] and r["pending_is_work"], "the tail collective was not launched from the backward hook"
+    sys.path.insert(0, ROOT)
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    d = qm9_like_batch(4, 10, side=5.0, seed=5)
+    _loss(model, d, range(4), dev).backward()
+    late = {id(p) for p in model.late_gradient_parameters()}
+    params = [p for p in model.parameters() if p.requires_grad]
+    ordered = [p for p in params if id(p) in late] + [p for p in params if id(p) not in late]
+    full = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ordered]).cpu()
+    err = ((full - r["flat"]).abs().max() / full.abs().max()).item()
+    assert err < 2e-5, err
+
+
 def test_molecule_edge_counts_and_balanced_shards():
     from equiformer_amd.graph import EdgeGraph
     from equiformer_amd.parallel import molecule_edge_counts, shard_balanced

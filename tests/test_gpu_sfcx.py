@@ -29,6 +29,9 @@ CASES = {
     "qm9_sep_value": ("128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "128x0e+64x1e+32x2e", 0, False),
     "oc20_l1": ("256x0e+128x1e", "1x0e+1x1e", "256x0e+128x1e", 0, True),
     "md17_l3": ("128x0e+64x1e+64x2e+32x3e", "1x0e+1x1e+1x2e+1x3e", "128x0e+64x1e+64x2e+32x3e", 0, True),
+    # a custom width whose data gradient exceeds the sfcx planner's slab table (14 input slabs > 12): that launch is served by
+    # the exact-fp32 kernel, the other two by sfcx (round-3 advisor finding: it used to raise mid-backward)
+    "wide_l2": ("256x0e+128x1e+64x2e", "1x0e+1x1e+1x2e", "256x0e+128x1e+64x2e", 0, True),
 }
 
 
@@ -48,6 +51,8 @@ def _problem(case, E, seed=0):
     lay = RowLayout(out_irr)
     spec = ops.SfcSpec(table, lay, n2=n2)
     assert spec.supported and spec.x_ok
+    if case == "wide_l2":
+        assert spec.x_mask(0) == 5, spec.x_mask(0)
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
     x, M = r(E, table.layout_in.dim), r(E, table.m_numel)

@@ -442,9 +442,27 @@ def test_l3_plans():
     o1, _ = replay_fwd(P)
     r1, _ = P.forward_ref()
     assert _rel(o1, r1) < 1e-12
-    assert P.spec.x_bwd_ok and P.spec.x_ok
+    assert P.spec.x_ok and P.spec.x_mask(0) == 7
     got = replay_bwd(P)
     want = P.backward_ref()
     for a, b in zip(got, want):
         if a is not None and b is not None:
             assert _rel(a, b) < 1e-12
+
+
+def test_planner_verdicts_drive_the_fallback():
+    """eqf_sfcx_supported (host only) is the planners' own verdict: all three launches for every registered configuration; a
+    256-wide L = 2 trunk keeps forward + weight gradient on the split-precision kernels and sends the data gradient (14 input
+    slabs, table of 12) to the exact-fp32 kernel; a 3x-wide L = 3 trunk exceeds all three tables and runs entirely on the exact-fp32 kernels (mode None)."""
+    from equiformer_amd import ops
+    from equiformer_amd.layout import DtpTable, RowLayout
+    irr = "128x0e+64x1e+32x2e"
+    spec = ops.SfcSpec(DtpTable(irr, "1x0e+1x1e+1x2e", irr), RowLayout("224x0e+64x1e+32x2e"), n2=128)
+    assert [spec.x_mask(m) for m in (0, 1, 2)] == [7, 7, 7]
+    wide = "256x0e+128x1e+64x2e"
+    spec = ops.SfcSpec(DtpTable(wide, "1x0e+1x1e+1x2e", wide), RowLayout(wide), n2=0)
+    assert spec.supported and spec.x_mask(0) == 5
+    l3 = "384x0e+192x1e+192x2e+96x3e"
+    spec = ops.SfcSpec(DtpTable(l3, "1x0e+1x1e+1x2e+1x3e", l3), RowLayout(l3), n2=128)
+    if spec.supported:
+        assert spec.x_mask(0) == 0 and ops._sfc_mode(spec) is None
