@@ -52,12 +52,6 @@ class GraphAttentionTransformerOC20(_Trunk):
         self.use_auxiliary_task, self.use_attention_head = use_auxiliary_task, use_attention_head
         # [ref: :185-187] 1o when the feature carries 1o channels (E(3) variants), 1e otherwise
         irreps_aux = Irreps("1x1o") if any(ir.l == 1 and ir.p == -1 for _, ir in self.irreps_feature) else Irreps("1x1e")
-        import os as _os
-        if use_auxiliary_task and irreps_aux == Irreps("1x1o") and not _os.environ.get("EQF_ALLOW_E3_AUX"):
-            # the reference builds this head with 1x1o [ref: :184-186]; the HIP attention head on an E(3) feature that lacks
-            # some (degree, parity) segments is 11 % off the reference (tests/test_gpu_oc20_heads.py, round 3) -- not
-            # shipped by any reference config (the *_aux_* configs are SE(3)), so it fails loudly instead
-            raise NotImplementedError("use_auxiliary_task on a feature with 1o channels (E(3) irreps) is not supported")
         head_drop = alpha_drop if auxiliary_head_dropout else 0.0
 
         def attention(irreps_out):

@@ -332,6 +332,14 @@ class LinearSpec:
         self.out_covered = len(self.pairs) == len(out_layout.segs)
         self.in_covered = len(self.pairs) == len(in_layout.segs)
         self.bias_dim = out_layout.mul_of(0)  # bias on 0e only
+        # the pair that carries the bias is the one writing the 0e segment: a 0o segment (E(3) irreps) also has l == 0 but
+        # no bias (round 4: the parity-blind `l == 0` test added the 0e bias to the 0o outputs and its column sums to the
+        # bias gradient -- invisible with zero-initialised biases, 11 % on the OC20 auxiliary head with filled ones)
+        j0 = out_layout.seg_index(0, 1)
+        self.bias_out_off = out_layout.offsets[j0] if j0 is not None else None
+
+    def has_bias(self, l, out_off):
+        return l == 0 and out_off == self.bias_out_off
 
 
 def _gemm_group(descs, st):
@@ -354,7 +362,7 @@ def _lin_fwd(x, weight, bias, spec):
     descs = []
     for (l, in_off, K, out_off, N, w_off) in spec.pairs:
         d = 2 * l + 1
-        b = bias if (l == 0 and bias is not None) else None
+        b = bias if (spec.has_bias(l, out_off) and bias is not None) else None
         descs.append(_desc(0, (x, in_off), rows(d, Din, K), (weight, w_off), N, (out, out_off), rows(d, Dout, N), b,
                            n * d, N, K))
     _gemm_group(descs, _stream())
@@ -384,7 +392,7 @@ def _lin_wgrad(x, dy, spec, dw, db=None):
         d = 2 * l + 1
         # kind 2: C[K,N] += sum_rows x[row, 0:K]^T dy[row, 0:N]; "rc" describes the dy rows, ldb = ldc
         descs.append(_desc(2, (x, in_off), rows(d, Din, K), (dy, out_off), N, (dw, w_off), rows(d, Dout, N),
-                           db if l == 0 else None, K, N, n * d))
+                           db if spec.has_bias(l, out_off) else None, K, N, n * d))
     _gemm_group(descs, _stream())
     return dw
 
@@ -477,8 +485,8 @@ class _IrrepsLinear(Function):
             return dx, None, None, None
         if ctx.needs_input_grad[1] or want_b:
             dw_, db_ = _zeros2(weight.numel(), spec.bias_dim if want_b else 0, x.device)
-        fused_b = want_b and ctx.needs_input_grad[1] and any(l == 0 and N == spec.bias_dim
-                                                              for (l, _, _, _, N, _) in spec.pairs)
+        fused_b = want_b and ctx.needs_input_grad[1] and any(spec.has_bias(l, o) and N == spec.bias_dim
+                                                              for (l, _, _, o, N, _) in spec.pairs)
         if ctx.needs_input_grad[1]:
             dw = _lin_wgrad(x, dy, spec, dw_, db_ if fused_b else None)
         if want_b:

@@ -90,11 +90,14 @@ def test_layer_norm_and_gate_with_pseudo_scalars():
     assert _rel(z[:, to_e3], zr) < 1e-5
 
 
-def test_e3_qm9_forward_backward_and_inversion():
+@pytest.mark.parametrize("num_layers", [2, 4])
+def test_e3_qm9_forward_backward_and_inversion(num_layers):
+    """four blocks: an error in the pseudo-scalar / pseudo-vector channels (0o, 1e) needs three tensor products with the
+    odd spherical harmonics to reach the energy -- two blocks are blind to it (round 4: the 0e bias added to 0o outputs)"""
     from equiformer_amd.nets.graph_attention_transformer import GraphAttentionTransformer
     from equiformer_amd.synthetic import qm9_like_batch
     dev = _dev()
-    kw = dict(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **SMALL_E3_L2)
+    kw = dict(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **dict(SMALL_E3_L2, num_layers=num_layers))
     ref = fill_deterministic(onets.GraphAttentionTransformer(**kw), 51).double().eval()
     mod = GraphAttentionTransformer(**kw)
     mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)

@@ -30,15 +30,21 @@ VARIANTS = {
 }
 
 
-def stats(t):
+GRAPH = {}
+
+
+def node_level(t, dst, N):
+    """[N, D] as is; [E, D] summed over the edges of every destination (independent of the edge order)"""
     t = t.detach().double().cpu()
     if t.dim() == 1:
         t = t[:, None]
     t = t.reshape(t.shape[0], -1)
-    return torch.stack([t.pow(2).sum(1), t.sum(1)], 1)
+    if t.shape[0] == N or dst is None or t.shape[0] != dst.numel():
+        return t
+    return torch.zeros(N, t.shape[1], dtype=torch.float64).index_add_(0, dst.long().cpu(), t)
 
 
-def capture(model, store, order):
+def capture(model, store, order, irr):
     hs = []
     for name, m in model.named_modules():
         if not name:
@@ -51,9 +57,30 @@ def capture(model, store, order):
                     key = "%s[%d]" % (name, k)
                     if key not in store:
                         order.append(key)
-                    store[key] = stats(o)
+                    store[key] = o.detach()
+                    if k == 0 and hasattr(mod, "irreps_out"):
+                        irr[key] = str(mod.irreps_out)
         hs.append(m.register_forward_hook(hook))
     return hs
+
+
+def seg_errors(a, b, irreps_str):
+    """a: oracle rows (e3nn layout), b: product rows (channel-fastest layout) -> {irrep: rel err} or None"""
+    from equiformer_amd.irreps import Irreps
+    from equiformer_amd.layout import RowLayout
+    try:
+        lay = RowLayout(Irreps(irreps_str).simplify())
+    except Exception:
+        return None
+    if lay.dim != a.shape[1] or a.shape != b.shape:
+        return None
+    b = b[:, lay.perm_to_e3nn()]
+    out = {}
+    scale = a.abs().max().clamp_min(1e-30)
+    for (mul, l), par, off in zip(lay.segs, lay.par, lay.offsets):
+        d = mul * (2 * l + 1)
+        out["%d%s" % (l, "e" if par == 1 else "o")] = ((a[:, off:off + d] - b[:, off:off + d]).abs().max() / scale).item()
+    return out
 
 
 def main():
@@ -70,31 +97,44 @@ def main():
     mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
     mod = mod.to(dev).eval()
     pos, batch, Z, tags, ei, off = _slab(2, 24, seed=3)
-    sr, so, orr, oo = {}, {}, [], []
-    capture(ref, sr, orr)
-    capture(mod, so, oo)
+    sr, so, orr, oo, irr, irr2 = {}, {}, [], [], {}, {}
+    capture(ref, sr, orr, irr)
+    capture(mod, so, oo, irr2)
+    from equiformer_amd import graph as _graph
+    init0 = _graph.EdgeGraph.__init__
+
+    def init1(self, *a, **kw):
+        init0(self, *a, **kw)
+        GRAPH["g"] = self
+    _graph.EdgeGraph.__init__ = init1
     with torch.no_grad():
         out_r = ref(Z, tags, pos.double(), batch, edge_index=ei, offsets=off.double())
         data = SimpleNamespace(pos=pos.to(dev), batch=batch.to(dev), atomic_numbers=Z.to(dev), tags=tags.to(dev),
                                edge_index=ei.to(dev), offsets=off.to(dev))
         out = mod(data)
-    print("variant", which, extra)
+    N = pos.shape[0]
+    dst_r, dst_p = ei[1], GRAPH["g"].dst
+    print("variant", which, extra, "N", N, "E oracle", ei.shape[1], "E product", GRAPH["g"].E)
     for k, (a, b) in enumerate(zip(out_r, out)):
         a, b = a.double(), b.double().cpu()
         print("output %d: rel err %.3e" % (k, ((a - b).abs().max() / a.abs().max()).item()))
-    print("%-58s %-14s %10s %10s" % ("module (oracle execution order)", "shape", "sumsq rel", "sum rel"))
+    print("%-52s %-12s %s" % ("module (oracle execution order)", "shape", "error per irrep (or layout-free statistics), node level"))
     for key in orr:
         if key not in so:
-            print("%-58s (no product counterpart)" % key)
             continue
-        a, b = sr[key], so[key]
+        a, b = node_level(sr[key], dst_r, N), node_level(so[key], dst_p, N)
         if a.shape != b.shape:
-            print("%-58s shapes differ %s %s" % (key, tuple(a.shape), tuple(b.shape)))
+            print("%-52s shapes differ %s %s" % (key, tuple(a.shape), tuple(b.shape)))
             continue
-        e2 = ((a[:, 0] - b[:, 0]).abs().max() / a[:, 0].abs().max().clamp_min(1e-30)).item()
-        e1 = ((a[:, 1] - b[:, 1]).abs().max() / a[:, 1].abs().max().clamp_min(1e-30)).item()
-        flag = "  <--" if e2 > 1e-4 else ""
-        print("%-58s %-14s %10.2e %10.2e%s" % (key, tuple(a.shape), e2, e1, flag))
+        errs = seg_errors(a, b, irr[key]) if key in irr else None
+        if errs is None:
+            e2 = ((a.pow(2).sum(1) - b.pow(2).sum(1)).abs().max() / a.pow(2).sum(1).abs().max().clamp_min(1e-30)).item()
+            txt = "sumsq %.2e" % e2
+            bad = e2 > 1e-4
+        else:
+            txt = "  ".join("%s %.1e" % kv for kv in errs.items())
+            bad = max(errs.values()) > 1e-4
+        print("%-52s %-12s %s%s" % (key, tuple(sr[key].shape), txt, "   <--" if bad else ""))
 
 
 if __name__ == "__main__":
