@@ -1,0 +1,341 @@
+// Pieces shared by the split-precision SeparableFCTP translation units (sfcx.hip: forward, weight gradient, first data-gradient
+// kernel; sfcx_bwd2.hip: the multi-wave data gradient): plane splitting, packed-weight layout, row-major tile I/O, the argument
+// tables of the data gradient and their planner.  Everything sits in an anonymous namespace: each unit gets its own copy.
+#pragma once
+#include "common.h"
+#include "prof.h"
+#include "sfc_common.h"
+#include <cstdio>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace sfcx {
+// sfcx_bwd2.hip: the multi-wave data gradient (d_out planes shared through LDS).  EQF_E_UNSUPPORTED = nothing launched, use the
+// one-wave kernel of sfcx.hip.  plan_only: host-side verdict without a launch.
+int bwd2_launch(const sfc::SfcCommon& C, const eqf_dtp_paths* P, int mode, float* dx, float* dw, float* dM, const void* packed,
+                bool plan_only, void* stream);
+}  // namespace sfcx
+
+namespace {
+using namespace sfc;
+
+template <int MODE>
+struct Planes;
+template <>
+struct Planes<0> {
+  static constexpr int A = 2, W = 3;
+};
+template <>
+struct Planes<1> {
+  static constexpr int A = 1, W = 1;
+};
+template <>
+struct Planes<2> {
+  static constexpr int A = 3, W = 3;
+};
+inline int mode_npw(int mode) { return mode == 1 ? 1 : 3; }
+
+// x = p[0] + p[1] + ... (+ residual below 2^-(8 NP) |x|): each plane is the bf16 rounding of what is left
+template <int NP>
+__device__ __forceinline__ void split_planes(const float (&v)[8], bf16x8 (&p)[NP]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float r = v[j];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const __bf16 h = (__bf16)r;
+      p[q][j] = h;
+      if (q + 1 < NP) r = r - (float)h;
+    }
+  }
+}
+
+// acc += sum over plane pairs (i, j) with i + j <= max(NA, NB) - 1, highest order (smallest terms) first
+template <int NA, int NB>
+__device__ __forceinline__ void mma_terms(const bf16x8 (&a)[NA], const bf16x8 (&b)[NB], f32x16& acc) {
+  constexpr int TOP = (NA > NB ? NA : NB) - 1;
+#pragma unroll
+  for (int s = TOP; s >= 0; --s)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int j = s - i;
+      if (j >= 0 && j < NB) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc, 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- packed weight planes
+// per degree:  Pf [K/16][Ncat/32][NPW][64 lanes][8]   B fragments of the forward    (lane: column n = 32 ct + (lane & 31),
+//                                                      k = 16 kt + 8 (lane >> 5) + j)
+//              Pb [K/32][Ncat/16][NPW][64 lanes][8]   A fragments of the data grad   (lane: row = 32 s + (lane & 31),
+//                                                      n = 16 nt + 8 (lane >> 5) + j)
+// of the concatenated [main | second consumer] weight [K, Ncat].  Offsets in bf16 elements.
+struct PkDeg {
+  long pf, pb;
+};
+inline long pack_layout(const SfcCommon& C, int npw, PkDeg (&pk)[SFC_MAX_DEG]) {
+  long off = 0;
+  for (int d = 0; d < C.ndeg; ++d) {
+    const long n = (long)C.deg[d].K * C.deg[d].Ncat * npw;
+    pk[d].pf = off, off += n;
+    pk[d].pb = off, off += n;
+  }
+  return off;
+}
+
+// coupling block of 32 edges -> wave-private LDS: Mt[row * MS + j] = cp[(e0 + row) * m_ld + j], j < len.  Lane = (column
+// r + 32 k, row parity): every load instruction covers two rows of up to 128 contiguous bytes; 16 loads in flight.
+__device__ __forceinline__ void stage_m(float* __restrict__ Mt, const int MS, const float* __restrict__ cp,
+                                        const unsigned m_ld, const int e0, const int elast, const int len,
+                                        const int r, const int hi) {
+  for (int k0 = 0; k0 < len; k0 += 32) {
+    const int j = k0 + r;
+    const bool jv = j < len;
+    const int jc = jv ? j : 0;
+    float v[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int e = min(e0 + 2 * p + hi, elast);
+      v[p] = cp[(size_t)e * m_ld + jc];
+    }
+    if (jv) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) Mt[(2 * p + hi) * MS + j] = v[p];
+    }
+  }
+}
+
+// A 32 rows x 32 floats tile between global memory and the layout of a 32x32 MFMA C fragment (lane (r, hi) holds, of row r,
+// the four 16-byte runs at columns 8 g4 + 4 hi), by way of a wave-private LDS tile: every global instruction then moves whole
+// 128-byte lines (8 rows per instruction) instead of 64 pieces of 32 bytes (a quarter of the address-unit work per byte;
+// profiles/r03: the piecewise loads and stores were ~50 % of the data-gradient kernel).  XT_LD = 36 floats keeps the
+// fragment-wise 16-byte LDS reads conflict free and the row-wise writes at most 2-way (tests/test_sfcx_tiles.py).
+constexpr int XT_LD = 36;
+constexpr int XT_FLOATS = 32 * XT_LD;
+#ifndef EQF_XB_TILE_IO
+#define EQF_XB_TILE_IO 1
+#endif
+// issue the four row-major loads of a tile (rows past elast re-read row elast)
+__device__ __forceinline__ void tile_fetch(f32x4 (&t)[4], const float* __restrict__ base, const unsigned ld, const int e0,
+                                           const int elast, const int lane) {
+  const int c = lane & 7, rr = lane >> 3;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const unsigned e = min(e0 + rr + 8 * it, elast);
+    t[it] = *reinterpret_cast<const f32x4*>(base + (e * ld + 4 * c));
+  }
+}
+// row-major registers -> LDS tile -> fragment registers
+__device__ __forceinline__ void tile_to_frag(float* __restrict__ T, const f32x4 (&t)[4], float (&v)[16], const int lane) {
+  const int c = lane & 7, rr = lane >> 3, r = lane & 31, hi = lane >> 5;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(T + ((rr + 8 * it) * XT_LD + 4 * c)) = t[it];
+  __syncthreads();
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(T + (r * XT_LD + 8 * g4 + 4 * hi));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[4 * g4 + j] = u[j];
+  }
+}
+// fragment registers -> LDS tile -> row-major stores of the rows e0 + row < E
+__device__ __forceinline__ void tile_store(float* __restrict__ T, const float (&v)[16], float* __restrict__ base,
+                                           const unsigned ld, const int e0, const int E, const int lane) {
+  const int c = lane & 7, rr = lane >> 3, r = lane & 31, hi = lane >> 5;
+  __syncthreads();
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+    *reinterpret_cast<f32x4*>(T + (r * XT_LD + 8 * g4 + 4 * hi)) = f32x4{v[4 * g4], v[4 * g4 + 1], v[4 * g4 + 2], v[4 * g4 + 3]};
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = rr + 8 * it;
+    const f32x4 u = *reinterpret_cast<const f32x4*>(T + (row * XT_LD + 4 * c));
+    if (e0 + row < E) *reinterpret_cast<f32x4*>(base + ((unsigned)(e0 + row) * ld + 4 * c)) = u;
+  }
+}
+
+// one wave per workgroup: LDS instructions of a wave execute in order, so write -> read of the wave's own tile needs no
+// s_barrier, only that the compiler keeps the order
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// 16 rows x 32 floats, row-major in memory (rows e_lo .. e_lo + 15, clamped to elast) -> lane (r, hi) gets column r of the rows
+// 8 hi .. 8 hi + 7: two 16-byte-per-lane loads of whole 128-byte lines and a wave-private LDS tile instead of eight 4-byte
+// loads that each touch two lines (weight gradient: both MFMA operands are "lane = column, 8 edges per lane")
+constexpr int XT16_FLOATS = 16 * XT_LD;
+#ifndef EQF_XW_TILE
+#define EQF_XW_TILE 1
+#endif
+struct Tile16 {
+  f32x4 t0, t1;
+};
+__device__ __forceinline__ void tile16_fetch(Tile16& t, const float* __restrict__ base, const unsigned ld, const int e_lo,
+                                             const int elast, const int lane) {
+  const int c = lane & 7, rr = lane >> 3;
+  t.t0 = *reinterpret_cast<const f32x4*>(base + ((unsigned)min(e_lo + rr, elast) * ld + 4 * c));
+  t.t1 = *reinterpret_cast<const f32x4*>(base + ((unsigned)min(e_lo + rr + 8, elast) * ld + 4 * c));
+}
+__device__ __forceinline__ void tile16_put(float* __restrict__ T, const Tile16& t, const int lane) {
+  const int c = lane & 7, rr = lane >> 3;
+  *reinterpret_cast<f32x4*>(T + (rr * XT_LD + 4 * c)) = t.t0;
+  *reinterpret_cast<f32x4*>(T + ((rr + 8) * XT_LD + 4 * c)) = t.t1;
+}
+__device__ __forceinline__ void tile16_get(const float* __restrict__ T, const int lane, float (&v)[8]) {
+  const int r = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = T[(8 * hi + j) * XT_LD + r];
+}
+
+// read a by-value argument block in place (kernarg segment): with several instantiated bodies hipcc otherwise copies the
+// struct to scratch and serves every dynamically indexed table lookup from there
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KERNARG_IN_PLACE(T)                                           \
+  const T& g = *(const T*)__builtin_amdgcn_kernarg_segment_ptr();     \
+  (void)g_byval
+#else
+#define KERNARG_IN_PLACE(T) const T& g = g_byval
+#endif
+
+// Dev build (-DEQF_XTRACE=1, tools/sfcx_trace.py): serialising clock samples around the two phases of a forward step -- all
+// operands arrived / matrix instructions retired -- for the first workgroups of one XCD.  Not compiled into the product.
+#ifndef EQF_XTRACE
+#define EQF_XTRACE 0
+#endif
+#if EQF_XTRACE
+__device__ __forceinline__ unsigned long long xt_clock() {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define XT_RETIRE(v) asm volatile("v_mov_b32 %0, %0" : "+v"(v))
+// non-serialising sample (only the scalar result is waited for): phase marks of the data-gradient item
+__device__ __forceinline__ unsigned long long xt_mark() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define XT_MARK()                                                    \
+  do {                                                               \
+    if (trace_on && lane == 0 && trace_n < 63) trace_p[++trace_n] = xt_mark(); \
+  } while (0)
+#else
+#define XT_MARK() \
+  do {            \
+  } while (0)
+#endif
+
+template <int N>
+struct IC {
+  static constexpr int value = N;
+};
+
+inline SfcOrder xcd_order(int nx, int ny, int& nblocks) {
+  SfcOrder o;
+  o.mode = 1, o.nx = nx, o.ny = ny;
+  o.per_xcd = (nx * ny + 7) / 8;
+  nblocks = 8 * o.per_xcd;
+  return o;
+}
+
+constexpr int XB_MAXGRP = 12;
+constexpr int XB_MAXPATH = 12;
+struct XBPath {
+  short deg, mlen;  // index into deg[]; d1 * d3
+  int krow;         // first row of the slab in W_l3
+  int w_off;        // offset of the slab's weights in the w row
+  int m_off;        // offset of the path's matrix in the coupling row
+};
+struct XBGroup {
+  int x_off;  // offset of the slab (segment + 32 c) in the x row
+  short mul, d1, npath, pad;
+  XBPath p[XB_MAXPATH];
+};
+struct XBwdArgs {
+  const float *x, *coupling, *w;
+  int x_ld, m_ld, w_ld, E;
+  const float *d1, *d2;
+  int ld1, ld2;
+  float *dx, *dw, *dM;
+  const __bf16* packed;
+  int ms;
+  SfcOrder ord;  // nx = edge tiles, ny = groups of this launch
+  struct Deg {
+    int d3, N1, Ncat, out1_off, nt;
+    long pb;
+  } deg[SFC_MAX_DEG];
+  XBGroup grp[XB_MAXGRP];
+#if EQF_XTRACE
+  unsigned long long* trace;
+#endif
+};
+
+float* const kDummyF = reinterpret_cast<float*>(16);  // non-null placeholder for tables built without data pointers
+
+// lane offsets are 32-bit element indices: every per-edge tensor must stay below 2^31 elements
+inline bool fits32(const SfcCommon& C) {
+  const long E = C.E;
+  const long big = (long)1 << 31;
+  return E * C.x_ld < big && E * C.w_ld < big && E * C.m_ld < big && E * C.ld1 < big && E * (long)C.ld2 < big;
+}
+
+inline int max_deg(const SfcCommon& C) {
+  int md = max_d1(C);
+  for (int d = 0; d < C.ndeg; ++d) md = C.deg[d].d3 > md ? C.deg[d].d3 : md;
+  return md;
+}
+
+inline int plan_bwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XBwdArgs& A, int& nblk, size_t& lds, int& ngrp_out) {
+  if (!fits32(C)) return EQF_E_UNSUPPORTED;
+  if (max_deg(C) > 7) return EQF_E_UNSUPPORTED;
+  PkDeg pk[SFC_MAX_DEG];
+  pack_layout(C, mode_npw(mode), pk);
+  memset(&A, 0, sizeof A);
+  A.x = C.x, A.coupling = C.coupling, A.w = C.w;
+  A.x_ld = C.x_ld, A.m_ld = C.m_ld, A.w_ld = C.w_ld, A.E = C.E;
+  A.d1 = C.o1, A.d2 = C.o2, A.ld1 = C.ld1, A.ld2 = C.ld2;
+  for (int d = 0; d < C.ndeg; ++d) {
+    const SfcDeg& D = C.deg[d];
+    A.deg[d].d3 = D.d3, A.deg[d].N1 = D.N1, A.deg[d].Ncat = D.Ncat, A.deg[d].out1_off = D.out1_off;
+    A.deg[d].nt = D.Ncat / 16, A.deg[d].pb = pk[d].pb;
+  }
+  int ngrp = 0, msmax = 1;
+  // distinct input segments; one group per 32-channel slab of a segment; paths sorted by output degree
+  int seg_off[EQF_MAX_SEG], nseg = 0;
+  for (int p = 0; p < P->npaths; ++p) {
+    bool found = false;
+    for (int s = 0; s < nseg; ++s) found |= seg_off[s] == P->in_off[p];
+    if (found) continue;
+    if (nseg >= EQF_MAX_SEG) return EQF_E_UNSUPPORTED;
+    seg_off[nseg++] = P->in_off[p];
+    const int mul = P->mul[p], d1 = 2 * P->l1[p] + 1;
+    if (mul % 32 != 0) return EQF_E_UNSUPPORTED;
+    for (int c = 0; c < mul; c += 32) {
+      if (ngrp >= XB_MAXGRP) return EQF_E_UNSUPPORTED;
+      XBGroup& G = A.grp[ngrp];
+      G.x_off = P->in_off[p] + c, G.mul = (short)mul, G.d1 = (short)d1, G.npath = 0;
+      for (int d = 0; d < C.ndeg; ++d)
+        for (int q = 0; q < P->npaths; ++q) {
+          if (P->in_off[q] != P->in_off[p] || P->l3[q] != C.deg[d].l3) continue;
+          if (G.npath >= XB_MAXPATH) return EQF_E_UNSUPPORTED;
+          XBPath& Q = G.p[G.npath++];
+          Q.deg = (short)d, Q.mlen = (short)(d1 * C.deg[d].d3);
+          Q.krow = P->out_ch[q] + c, Q.w_off = P->w_off[q] + c, Q.m_off = P->m_off[q];
+          if ((Q.mlen | 1) > msmax) msmax = Q.mlen | 1;
+        }
+      if (G.npath > 0) ++ngrp;
+    }
+  }
+  if (ngrp == 0) return EQF_E_BADARG;
+  ngrp_out = ngrp;
+  if ((C.x_ld | C.w_ld | C.ld1 | C.ld2) & 3) return EQF_E_UNSUPPORTED;  // the row-major tiles are read with 16-byte loads
+  A.ms = (msmax + 3) & ~3;  // the transposition tile behind the coupling block stays 16-byte aligned
+  lds = (size_t)(32 * A.ms + (1 + 5) * XT_FLOATS) * sizeof(float);  // coupling block + x / w / dx / dw tile + one d_out tile per m3
+  A.ord = xcd_order(eqf_cdiv(C.E, 32), ngrp, nblk);
+  return 0;
+}
+
+}  // namespace

@@ -36,6 +36,9 @@ int eqf_sfc_debug_buffer(void* device_u64x8);
  * numpy on these tables.  Returns the number of characters written or a negative error. */
 int eqf_sfcx_dev_plan(int kind, const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int E, int mode,
                       char* buf, int buflen);
+/* switches of the split-precision kernels: key 0 = data-gradient kernel (2 = the multi-wave kernel of csrc/sfcx_bwd2.hip where
+ * the operator fits it; anything else = the one-wave kernel, the default) */
+int eqf_sfcx_dev_set(int key, int value);
 /* gemm kernels: 1 no stores, 2 no MFMA */
 int eqf_gemm_debug_exp(int mask);
 

@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the split-precision SeparableFCTP kernels (csrc/sfcx.hip, sfcx_bwd2.hip) at the bench shapes:
+   python tools/bench_sfcx.py [E] [modes, e.g. 0,1]
+us / call of forward, data gradient (multi-wave kernel and, through the development switch, the one-wave kernel; their
+results are compared), weight gradient."""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from equiformer_amd import lib as _lib, ops  # noqa: E402
+from equiformer_amd.layout import DtpTable, RowLayout  # noqa: E402
+from equiformer_amd.lib import call  # noqa: E402
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 25354
+MODES = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+dev = torch.device("cuda:0")
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+L = _lib.load()
+
+
+def timeit(fn, n=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / n
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def run(name, irr, sh_irr, out_irr, n2, use_w, want_dM=False):
+    table = DtpTable(irr, sh_irr, irr)
+    lay = RowLayout(out_irr)
+    spec = ops.SfcSpec(table, lay, n2=n2)
+    assert spec.supported
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(E, table.layout_in.dim, generator=g).to(dev)
+    M = torch.randn(E, table.m_numel, generator=g).to(dev)
+    w = torch.randn(E, table.weight_numel, generator=g).to(dev) if use_w else None
+    weight = torch.randn(spec.weight_numel, generator=g).to(dev)
+    weight2 = torch.randn(spec.weight2_numel, generator=g).to(dev) if n2 else None
+    dweight = torch.zeros_like(weight)
+    dweight2 = torch.zeros_like(weight2) if n2 else None
+    o1 = torch.empty(E, lay.dim, device=dev)
+    o2 = torch.empty(E, n2, device=dev) if n2 else None
+    d1 = torch.randn(E, lay.dim, generator=g).to(dev)
+    d2 = torch.randn(E, n2, generator=g).to(dev) if n2 else None
+    dWl = ops._ptr_array((d[0], dweight.data_ptr() + 4 * o) for d, o in zip(spec.degs, spec.w_offs))
+    flops = sum(2.0 * E * (2 * l3 + 1) * K * ncat for (l3, K, _, ncat) in spec.degs)
+    for mode in MODES:
+        packed = ops._sfc_pack(weight, weight2, spec, mode)
+        PK = ctypes.c_void_p(packed.data_ptr())
+
+        def bwd(version):
+            L.eqf_sfcx_dev_set(0, version)
+            dx = torch.full_like(x, float("nan"))
+            dw = torch.full_like(w, float("nan")) if use_w else None
+            dM = torch.zeros_like(M) if want_dM else None
+            fn = lambda: call("eqf_sfcx_bwd_data", P(x), P(M), P(w), table.c_ref, PK, P(d1), lay.c_ref, P(d2), n2,  # noqa: E731
+                              P(dx), P(dw), P(dM), E, mode, st())
+            fn()
+            torch.cuda.synchronize()
+            res = (dx.clone(), dw.clone() if use_w else None, dM.clone() if want_dM else None)
+            us = timeit(fn)
+            L.eqf_sfcx_dev_set(0, 0)
+            return us, res
+        us1, r1 = bwd(1)
+        us2, r2 = bwd(2)
+        errs = ["%.1e" % rel(a, b) if a is not None else "-" for a, b in zip(r2, r1)]
+        fin = all(torch.isfinite(a).all().item() for a in r2 if a is not None)
+        print("%-10s mode %d%s bwd_data  one-wave %7.1f us   multi-wave %7.1f us  (%5.1f TFLOP/s)   multi vs one-wave: dx %s dw %s dM %s  finite %s"
+              % (name, mode, " dM" if want_dM else "", us1, us2, flops / us2 / 1e6, *errs, fin), flush=True)
+        if want_dM:
+            continue
+        fx = lambda: call("eqf_sfcx_fwd", P(x), P(M), P(w), table.c_ref, PK, None, None, P(o1), lay.c_ref, P(o2), n2, E,  # noqa: E731
+                          mode, st())
+        wx = lambda: call("eqf_sfcx_bwd_weight", P(x), P(M), P(w), table.c_ref, P(d1), lay.c_ref, P(d2), n2, dWl,  # noqa: E731
+                          P(dweight2), E, mode, st())
+        for tag, fn in (("fwd", fx), ("bwd_weight", wx)):
+            us = timeit(fn)
+            print("%-10s mode %d %-10s %7.1f us  (%5.1f TFLOP/s)" % (name, mode, tag, us, flops / us / 1e6), flush=True)
+
+
+run("sep_act", "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "224x0e+64x1e+32x2e", 128, True)
+run("sep_value", "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "128x0e+64x1e+32x2e", 0, False)
+if "--dm" in sys.argv:
+    run("sep_act", "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "224x0e+64x1e+32x2e", 128, True, want_dM=True)
