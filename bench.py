@@ -502,12 +502,13 @@ def main():
                                 "avg_launch_ms": sc["total_ms"] / sc["launches"], "algorithmic_bytes_per_launch": byts}
         # the widest E-row GEMM with a memory A operand and an [N, K] weight = the radial MLP's last layer
         rad = [(n2, r2) for n2, r2 in allprof.items()
-               if (n2.startswith("gemm_rows_") and n2.endswith("_mem_nk")) or n2.startswith("gemmx_radial")]
+               if (n2.startswith("gemm_rows_") and n2.endswith("_mem_nk")) or n2 in ("gemmx_group_nk_edge", "gemm_group_nk")]
         if rad:
             n2, r2 = max(rad, key=lambda kv: kv[1]["flops"] / kv[1]["launches"])
             tf = r2["flops"] / r2["total_ms"] / 1e9
             pk, _ = kernel_peak(n2, args.matrix_mode)
-            extra["radial_mlp"] = {"kernel": n2 + " (radial MLP 64 -> 960)", "bound": "mfma", "achieved": tf,
+            extra["radial_mlp"] = {"kernel": n2 + " (edge-row nn.Linear launches of the radial bank: 128 -> G x 64, G x (64 -> 64), "
+                                             "G x (64 -> 960); the last is 94 % of their flops)", "bound": "mfma", "achieved": tf,
                                    "peak": pk, "unit": "TFLOP/s", "frac": tf / pk, "frac_of_fp32_peak": tf / PEAK_F32_MFMA_TFLOPS,
                                    "avg_launch_ms": r2["total_ms"] / r2["launches"]}
         # whole step against the HBM roofline of SURVEY 8d: 3.0 MB algorithmic bytes per molecule-step at E = 200

@@ -1,0 +1,625 @@
+// Per-degree / dense linears of the hot path on the bf16 matrix cores (split precision), grouped launches.
+//
+//   kind 0:  C[i,n] (=|+=) sum_k A[i,k] B[k,n] (+ bias[n])       LinearRS forward (weight [K,N]); nn.Linear data gradient
+//   kind 1:  C[i,n] (=|+=) sum_k A[i,k] B[n,k] (+ bias[n])       LinearRS data gradient; nn.Linear forward (weight [N,K])
+//   kind 2:  C[m,n] += sum_i A[i,m] B[i,n], colsum(B) optional    LinearRS weight gradient (+ bias gradient)
+//   kind 3:  same, colsum(A) optional                            nn.Linear weight gradient (dW[out,in] = dy^T x, db = colsum dy)
+//
+// [ref: LinearRS / FullyConnectedTensorProductRescale, nets/tensor_product_rescale.py:125-136,171-174; torch.nn.Linear inside
+//  RadialProfile, nets/radial_func.py:46-49; their autograd backward]
+//
+// Same contract as gemm.hip's eqf_gemm_group (exact-fp32 MFMA, kept as the cross-check and the `fp32` matrix mode); here the
+// matrix steps run on v_mfma_f32_32x32x16_bf16 -- 16 k per instruction instead of 2, on the matrix pipe instead of the VALU's
+// FMA lanes -- with fp32 operands split into bf16 planes exactly as in sfcx.hip:
+//   mode 0 (split)   activations 2 planes, weights 3 planes, 5 products (two activation operands: 2 + 2 planes, 3 products)
+//   mode 1 (bf16)    1 + 1 planes: plain bf16 operands, fp32 accumulation (BASELINE config #2 / the reference's AMP linears)
+//   mode 2 (split6)  3 + 3 planes
+// Why: the node-row linears (2 304 rows) are latency chains -- ~7 us fixed + 1.45 us per 32-deep K step with the fp32 MFMA
+// (profiles/r03/r03_u_*), 104 launches = 2.7 ms of the 13 ms QM9 step; a K step here is two matrix instructions deep.
+//
+// Tiling: 64 x 64 output tile per workgroup of four waves (32 x 32 each), K in steps of 32 through a double-buffered LDS
+// image [plane][row / column][k] with k contiguous (80-byte rows: conflict-free 16-byte fragment reads); the global loads of
+// step s + 1 are in flight during the matrix instructions of step s (registers), one barrier per step.  Operands are split
+// where they are staged (VALU, once per tile element).  Loaders:
+//   kc  source contiguous along k (A rows; [N,K] weights): 16-byte loads along k, 8-byte LDS writes per plane
+//   ks  source contiguous along the tile's row / column index (weights [K,N]; both operands of the weight gradient, whose
+//       reduction index is the feature row): lane = column, eight 4-byte loads down the reduction index (each a coalesced
+//       256-byte run), one 16-byte LDS write per plane; the bias gradient's column sums are taken from the fp32 registers.
+// Compiled with -fno-slp-vectorize (no packed-FP32 VALU beside bf16 MFMAs, as sfcx.hip).
+#include "sfcx_common.h"
+
+namespace {
+
+constexpr int GX_BK = 32;
+constexpr int GX_LDK = 40;       // bf16 elements per LDS row: 32 + 8 (80 bytes)
+constexpr int GX_T = 64;         // tile edge (rows and columns)
+constexpr int GX_ROW = GX_T * GX_LDK;
+constexpr int GX_MAXP = 8;
+
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+struct GRows {
+  const float* base;
+  int d, ld, inner;
+};
+
+struct GXP {          // one problem
+  GRows A, B, C;      // rows kinds: A rows x K, B plain (ld = ldb), C rows x N.  tn kinds: A: K rows x M, B: K rows x N
+  const float* bias;  // rows kinds: bias[N] or null
+  float* cs;          // tn kinds: column-sum accumulator (of B for kind 2, of A for kind 3) or null
+  float* Cw;          // tn kinds: C plain [M,N]
+  int ldc;
+  int M, N, K;        // tn kinds: K = number of reduction rows
+  int accumulate, kind;
+  int vecA, vecB;
+  int steps_per_split;
+};
+struct GXGroup {
+  int n;
+  int zoff[GX_MAXP + 1];  // tn: blockIdx.z -> (problem, split)
+  GXP p[GX_MAXP];
+};
+
+template <int NP>
+__device__ __forceinline__ void split_n(const float* v, int n, __bf16 (*p)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j >= n) break;
+    float r = v[j];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const __bf16 h = (__bf16)r;
+      p[q][j] = h;
+      if (q + 1 < NP) r = r - (float)h;
+    }
+  }
+}
+
+// ---- kc: 64 tile rows (two-level row index x0 + xr), 32 k contiguous in memory; thread = (row xr0 + 32 pass, k quad kq)
+template <int NP>
+struct LoaderKC {
+  float4 v[2];
+  long roff[2];
+  bool rv[2];
+  __device__ __forceinline__ void init(const GRows& R, int x0, int X) {
+    const int xr0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int x = x0 + xr0 + 32 * pass;
+      rv[pass] = x < X;
+      roff[pass] = row_off2(rv[pass] ? x : x0, R.d, R.ld, R.inner);
+    }
+  }
+  __device__ __forceinline__ void issue(const GRows& R, int k0, int K, bool vec) {
+    const int kq = threadIdx.x & 7;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int krem = K - (k0 + 4 * kq);
+      if (rv[pass] && krem > 0) {
+        const float* p = R.base + roff[pass] + k0 + 4 * kq;
+        if (vec && krem >= 4) {
+          r = *reinterpret_cast<const float4*>(p);
+        } else {
+          r.x = p[0];
+          if (krem > 1) r.y = p[1];
+          if (krem > 2) r.z = p[2];
+          if (krem > 3) r.w = p[3];
+        }
+      }
+      v[pass] = r;
+    }
+  }
+  __device__ __forceinline__ void commit(__bf16* __restrict__ T) const {  // T: [NP][64][GX_LDK]
+    const int kq = threadIdx.x & 7, xr0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const float f[4] = {v[pass].x, v[pass].y, v[pass].z, v[pass].w};
+      __bf16 p[NP][8];
+      split_n<NP>(f, 4, p);
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        *reinterpret_cast<bf16x4_t*>(T + q * GX_ROW + (xr0 + 32 * pass) * GX_LDK + 4 * kq) =
+            bf16x4_t{p[q][0], p[q][1], p[q][2], p[q][3]};
+    }
+  }
+};
+
+// ---- ks: 32 reduction rows (two-level index k0 + k) x 64 tile columns contiguous in memory; thread = (column x, k group kg)
+template <int NP>
+struct LoaderKS {
+  float v[8];
+  float cs;  // running column sum of the fp32 values this thread staged (bias gradients)
+  __device__ __forceinline__ void init() { cs = 0.f; }
+  __device__ __forceinline__ void issue(const GRows& R, int k0, int K, int x0, int X) {
+    const int x = x0 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+    const bool xv = x < X;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + 8 * kg + j;
+      float r = 0.f;
+      if (xv && k < K) r = R.base[row_off2(k, R.d, R.ld, R.inner) + x];
+      v[j] = r;
+    }
+  }
+  __device__ __forceinline__ void commit(__bf16* __restrict__ T, bool want_cs) {
+    const int x = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    if (want_cs) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cs += v[j];
+    }
+    __bf16 p[NP][8];
+    split_n<NP>(v, 8, p);
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+      *reinterpret_cast<bf16x8*>(T + q * GX_ROW + x * GX_LDK + 8 * kg) =
+          bf16x8{p[q][0], p[q][1], p[q][2], p[q][3], p[q][4], p[q][5], p[q][6], p[q][7]};
+  }
+};
+
+template <int NA, int NB>
+__device__ __forceinline__ void gx_mma(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs, int wm0, int wn0,
+                                       f32x16& acc) {
+  const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int kt = 0; kt < GX_BK / 16; ++kt) {
+    bf16x8 a[NA], b[NB];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) a[q] = *reinterpret_cast<const bf16x8*>(As + q * GX_ROW + (wm0 + r) * GX_LDK + 16 * kt + 8 * hi);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bs + q * GX_ROW + (wn0 + r) * GX_LDK + 16 * kt + 8 * hi);
+    mma_terms<NA, NB>(a, b, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ rows kernels (kinds 0, 1)
+template <int MODE, int BKIND>
+__global__ __launch_bounds__(256) void gemmx_rows_kernel(const GXGroup g_byval) {
+  KERNARG_IN_PLACE(GXGroup);
+  constexpr int NA = Planes<MODE>::A, NB = Planes<MODE>::W;
+  const GXP& P = g.p[blockIdx.z];
+  const int m0 = blockIdx.x * GX_T, n0 = blockIdx.y * GX_T;
+  if (m0 >= P.M || n0 >= P.N) return;
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][NA * GX_ROW];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NB * GX_ROW];
+  const int wave = threadIdx.x >> 6;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+
+  LoaderKC<NA> la;
+  LoaderKC<NB> lbk;
+  LoaderKS<NB> lbs;
+  la.init(P.A, m0, P.M);
+  la.issue(P.A, 0, P.K, P.vecA);
+  if constexpr (BKIND == 1) {
+    lbk.init(P.B, n0, P.N);
+    lbk.issue(P.B, 0, P.K, P.vecB);
+  } else {
+    lbs.init();
+    lbs.issue(P.B, 0, P.K, n0, P.N);
+  }
+  la.commit(As[0]);
+  if constexpr (BKIND == 1) lbk.commit(Bs[0]);
+  else lbs.commit(Bs[0], false);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < P.K; k0 += GX_BK) {
+    const bool more = k0 + GX_BK < P.K;
+    if (more) {
+      la.issue(P.A, k0 + GX_BK, P.K, P.vecA);
+      if constexpr (BKIND == 1) lbk.issue(P.B, k0 + GX_BK, P.K, P.vecB);
+      else lbs.issue(P.B, k0 + GX_BK, P.K, n0, P.N);
+    }
+    gx_mma<NA, NB>(As[cur], Bs[cur], wm0, wn0, acc);
+    if (more) {
+      la.commit(As[cur ^ 1]);
+      if constexpr (BKIND == 1) lbk.commit(Bs[cur ^ 1]);
+      else lbs.commit(Bs[cur ^ 1], false);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: accumulator register q of lane (r, hi) = tile row (q & 3) + 8 (q >> 2) + 4 hi, column r
+  const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+  const int col = n0 + wn0 + r;
+  if (col >= P.N) return;
+  const float bv = P.bias ? P.bias[col] : 0.f;
+  const bool flat_c = P.C.d == 1;
+  const SmallDiv cdiv(P.C.d);
+  float* const cbase = const_cast<float*>(P.C.base);
+  const int rb = m0 + wm0 + 4 * hi;
+  long off0;
+  int rem0 = 0;
+  if (flat_c) {
+    off0 = (long)rb * P.C.ld;
+  } else {
+    const int qb = rb / P.C.d;
+    rem0 = rb - qb * P.C.d;
+    off0 = (long)qb * P.C.ld;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int dr = (q & 3) + 8 * (q >> 2);
+    if (rb + dr < P.M) {
+      long off;
+      if (flat_c) {
+        off = off0 + (long)dr * P.C.ld;
+      } else {
+        const int t = rem0 + dr, dq = cdiv.div(t);
+        off = off0 + (long)dq * P.C.ld + (long)(t - dq * P.C.d) * P.C.inner;
+      }
+      float* p = cbase + off + col;
+      float v = acc[q] + bv;
+      if (P.accumulate) v += *p;
+      *p = v;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------- weight gradients (kinds 2, 3)
+template <int MODE>
+__global__ __launch_bounds__(256) void gemmx_tn_kernel(const GXGroup g_byval) {
+  KERNARG_IN_PLACE(GXGroup);
+  constexpr int NA = Planes<MODE>::A;  // both operands are activations
+  int pi = 0;
+  while (pi + 1 < g.n && (int)blockIdx.z >= g.zoff[pi + 1]) ++pi;
+  const GXP& P = g.p[pi];
+  const int m0 = blockIdx.x * GX_T, n0 = blockIdx.y * GX_T;
+  if (m0 >= P.M || n0 >= P.N) return;
+  const int bz = (int)blockIdx.z - g.zoff[pi];
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][NA * GX_ROW];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NA * GX_ROW];
+  const int wave = threadIdx.x >> 6;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  const int total = (P.K + GX_BK - 1) / GX_BK;
+  const int s_beg = bz * P.steps_per_split;
+  const int s_end = min(total, s_beg + P.steps_per_split);
+  if (s_beg >= s_end) return;
+  const bool csA = P.kind == 3 && P.cs != nullptr && blockIdx.y == 0;
+  const bool csB = P.kind == 2 && P.cs != nullptr && blockIdx.x == 0;
+  LoaderKS<NA> la, lb;
+  la.init();
+  lb.init();
+  la.issue(P.A, s_beg * GX_BK, P.K, m0, P.M);
+  lb.issue(P.B, s_beg * GX_BK, P.K, n0, P.N);
+  la.commit(As[0], csA);
+  lb.commit(Bs[0], csB);
+  __syncthreads();
+  int cur = 0;
+  for (int s = s_beg; s < s_end; ++s) {
+    const bool more = s + 1 < s_end;
+    if (more) {
+      la.issue(P.A, (s + 1) * GX_BK, P.K, m0, P.M);
+      lb.issue(P.B, (s + 1) * GX_BK, P.K, n0, P.N);
+    }
+    gx_mma<NA, NA>(As[cur], Bs[cur], wm0, wn0, acc);
+    if (more) {
+      la.commit(As[cur ^ 1], csA);
+      lb.commit(Bs[cur ^ 1], csB);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // column sums: the four k groups of a column add up through atomics (exact fp32 values, not the planes)
+  {
+    const int x = threadIdx.x & 63;
+    if (csA && m0 + x < P.M) atomicAdd(P.cs + m0 + x, la.cs);
+    if (csB && n0 + x < P.N) atomicAdd(P.cs + n0 + x, lb.cs);
+  }
+  const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+  const int col = n0 + wn0 + r;
+  if (col >= P.N) return;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = m0 + wm0 + (q & 3) + 8 * (q >> 2) + 4 * hi;
+    if (row < P.M) atomicAdd(P.Cw + (long)row * P.ldc + col, acc[q]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ direct kernels (node rows)
+// The node-row linears (2 304 rows x (2l+1)) are not matrix work: ~12 us per launch whatever the matrix rate (fp32 MFMA 12.8 us,
+// split planes 12.3 us, tools/gemm_shapes.py).  Experiment of round 4, kept behind eqf_gemmx_dev_set(0, 0): ONE WAVE owns a
+// 32 x 32 output tile and issues the loads of a whole 128-deep K chunk (operand fragments straight in MFMA layout, no LDS, no
+// barrier) before it multiplies -- one round trip per chunk, ~1 000 independent waves per launch.  Measured: the same 12.7 us
+// (with loads behind per-lane bounds branches: 16 us, hipcc waits for them at the end of each branch); the floor of these
+// launches is neither the K loop nor the barriers.
+constexpr int GD_KC = 128;  // K chunk held in registers (8 fragments of 16)
+
+// Preconditions (checked on the host, else the LDS-tiled kernel runs): K a multiple of 16 and 16-byte-aligned rows, so that every
+// load is unconditional (rows / columns past the edge are clamped to a valid one and never stored): a load behind a per-lane
+// branch makes hipcc wait for it at the end of the branch, and the "all loads of the chunk in flight" is gone.
+template <int MODE, int BKIND>
+__global__ __launch_bounds__(64, 2) void gemmx_rows_direct_kernel(const GXGroup g_byval) {
+  KERNARG_IN_PLACE(GXGroup);
+  constexpr int NA = Planes<MODE>::A, NB = Planes<MODE>::W;
+  const GXP& P = g.p[blockIdx.z];
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  if (m0 >= P.M || n0 >= P.N) return;
+  const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
+  const int row = min(m0 + r, P.M - 1), col = min(n0 + r, P.N - 1);
+  const float* const ap = P.A.base + row_off2(row, P.A.d, P.A.ld, P.A.inner) + 8 * hi;
+  const float* const bp = BKIND == 1 ? P.B.base + (long)col * P.B.ld + 8 * hi : P.B.base + (long)(8 * hi) * P.B.ld + col;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  for (int kc = 0; kc < P.K; kc += GD_KC) {
+    float a[GD_KC / 16][8], b[GD_KC / 16][8];
+    const int kend = min(P.K - kc, GD_KC);
+#pragma unroll
+    for (int kt = 0; kt < GD_KC / 16; ++kt) {
+      if (16 * kt < kend) {  // uniform
+        const int k = kc + 16 * kt;
+        const float4 u0 = *reinterpret_cast<const float4*>(ap + k);
+        const float4 u1 = *reinterpret_cast<const float4*>(ap + k + 4);
+        a[kt][0] = u0.x, a[kt][1] = u0.y, a[kt][2] = u0.z, a[kt][3] = u0.w;
+        a[kt][4] = u1.x, a[kt][5] = u1.y, a[kt][6] = u1.z, a[kt][7] = u1.w;
+        if constexpr (BKIND == 1) {  // B [N, K]: k contiguous
+          const float4 w0 = *reinterpret_cast<const float4*>(bp + k);
+          const float4 w1 = *reinterpret_cast<const float4*>(bp + k + 4);
+          b[kt][0] = w0.x, b[kt][1] = w0.y, b[kt][2] = w0.z, b[kt][3] = w0.w;
+          b[kt][4] = w1.x, b[kt][5] = w1.y, b[kt][6] = w1.z, b[kt][7] = w1.w;
+        } else {  // B [K, N]: lane = column, eight rows down k (each a 128-byte run over the 32 columns)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) b[kt][j] = bp[(unsigned)(k + j) * (unsigned)P.B.ld];  // (32-bit offsets: one address register pair)
+        }
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < GD_KC / 16; ++kt) {
+      if (16 * kt < kend) {  // uniform
+        bf16x8 pa[NA], pb[NB];
+        split_planes<NA>(a[kt], pa);
+        split_planes<NB>(b[kt], pb);
+        mma_terms<NA, NB>(pa, pb, acc);
+      }
+    }
+  }
+  if (n0 + r >= P.N) return;
+  const int ccol = n0 + r;
+  const float bv = P.bias ? P.bias[ccol] : 0.f;
+  const bool flat_c = P.C.d == 1;
+  const SmallDiv cdiv(P.C.d);
+  float* const cbase = const_cast<float*>(P.C.base);
+  const int rb = m0 + 4 * hi;
+  long off0;
+  int rem0 = 0;
+  if (flat_c) {
+    off0 = (long)rb * P.C.ld;
+  } else {
+    const int qb = rb / P.C.d;
+    rem0 = rb - qb * P.C.d;
+    off0 = (long)qb * P.C.ld;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int dr = (q & 3) + 8 * (q >> 2);
+    if (rb + dr < P.M) {
+      long off;
+      if (flat_c) {
+        off = off0 + (long)dr * P.C.ld;
+      } else {
+        const int t = rem0 + dr, dq = cdiv.div(t);
+        off = off0 + (long)dq * P.C.ld + (long)(t - dq * P.C.d) * P.C.inner;
+      }
+      float* p = cbase + off + ccol;
+      float v = acc[q] + bv;
+      if (P.accumulate) v += *p;
+      *p = v;
+    }
+  }
+}
+
+// weight gradients: one wave per (32 x 32 tile of C, chunk of GD_KC reduction rows); both operands "lane = column, eight rows
+// down the reduction index"; column sums (bias gradients) from the fp32 registers; fp32 atomics into C.  Loads unconditional
+// (clamped row / column), rows past the end zeroed by a select.
+template <int MODE>
+__global__ __launch_bounds__(64, 2) void gemmx_tn_direct_kernel(const GXGroup g_byval) {
+  KERNARG_IN_PLACE(GXGroup);
+  constexpr int NA = Planes<MODE>::A;
+  int pi = 0;
+  while (pi + 1 < g.n && (int)blockIdx.z >= g.zoff[pi + 1]) ++pi;
+  const GXP& P = g.p[pi];
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  if (m0 >= P.M || n0 >= P.N) return;
+  const int i0 = ((int)blockIdx.z - g.zoff[pi]) * GD_KC;
+  if (i0 >= P.K) return;
+  const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
+  const int mcol = min(m0 + r, P.M - 1), ncol = min(n0 + r, P.N - 1);
+  const int kend = min(P.K - i0, GD_KC);
+  float a[GD_KC / 16][8], b[GD_KC / 16][8];
+  // two-level reduction rows i = q d + rem: (q, rem) of this lane's first row, then stepped (the two operands share d only by
+  // convention, so each keeps its own)
+  const int ifirst = i0 + 8 * hi;
+  int qa = ifirst / P.A.d, ra = ifirst - qa * P.A.d;
+  int qb = ifirst / P.B.d, rb = ifirst - qb * P.B.d;
+#pragma unroll
+  for (int kt = 0; kt < GD_KC / 16; ++kt) {
+    if (16 * kt < kend) {  // uniform
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = ifirst + 16 * kt + j;
+        const bool iv = i < P.K;
+        const long oa = iv ? (long)qa * P.A.ld + (long)ra * P.A.inner : 0;
+        const long ob = iv ? (long)qb * P.B.ld + (long)rb * P.B.inner : 0;
+        const float va = P.A.base[oa + mcol], vb = P.B.base[ob + ncol];
+        a[kt][j] = iv ? va : 0.f;
+        b[kt][j] = iv ? vb : 0.f;
+        ++ra, ++rb;
+        if (ra == P.A.d) ra = 0, ++qa;
+        if (rb == P.B.d) rb = 0, ++qb;
+      }
+      // the other half-wave's eight rows lie between this step's and the next step's
+      {
+        const int sa = ra + 8, sb = rb + 8;
+        const int da = sa / P.A.d, db = sb / P.B.d;
+        qa += da, ra = sa - da * P.A.d;
+        qb += db, rb = sb - db * P.B.d;
+      }
+    }
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  float csa = 0.f, csb = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < GD_KC / 16; ++kt) {
+    if (16 * kt < kend) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) csa += a[kt][j], csb += b[kt][j];
+      bf16x8 pa[NA], pb[NA];
+      split_planes<NA>(a[kt], pa);
+      split_planes<NA>(b[kt], pb);
+      mma_terms<NA, NA>(pa, pb, acc);
+    }
+  }
+  const bool mv = m0 + r < P.M, nv = n0 + r < P.N;
+  if (P.cs != nullptr) {
+    if (P.kind == 3 && blockIdx.y == 0) {
+      csa += __shfl_xor(csa, 32);
+      if (hi == 0 && mv) atomicAdd(P.cs + mcol, csa);
+    }
+    if (P.kind == 2 && blockIdx.x == 0) {
+      csb += __shfl_xor(csb, 32);
+      if (hi == 0 && nv) atomicAdd(P.cs + ncol, csb);
+    }
+  }
+  if (!nv) return;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = m0 + (q & 3) + 8 * (q >> 2) + 4 * hi;
+    if (row < P.M) atomicAdd(P.Cw + (long)row * P.ldc + ncol, acc[q]);
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool rows_vec_ok(const float* base, const eqf_rows& r) { return aligned16(base) && (r.ld % 4 == 0) && (r.inner % 4 == 0); }
+
+}  // namespace
+
+// development switch (eqf_gemmx_dev_set key 0): 0 = the one-wave-per-tile kernels for node-row problems, anything else = the
+// LDS-tiled kernels for every problem (the default: the two measure the same, tools/gemm_shapes.py, profiles/r04/r04_j_*)
+static int g_gemmx_no_direct = 1;
+
+extern "C" {
+
+int eqf_gemmx_dev_set(int key, int value) {
+  if (key == 0) {
+    g_gemmx_no_direct = value;
+    return 0;
+  }
+  return EQF_E_BADARG;
+}
+
+int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
+  if (!d || n < 1 || n > GX_MAXP || mode < 0 || mode > 2) return EQF_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n; ++i) {
+    if (d[i].kind < 0 || d[i].kind > 3) return EQF_E_BADARG;
+    if (!d[i].A || !d[i].B || !d[i].C || d[i].ra.d < 1 || d[i].rc.d < 1) return EQF_E_BADARG;
+  }
+  static thread_local GXGroup G;
+  for (int kind = 0; kind < 2; ++kind) {
+    memset(&G, 0, sizeof G);
+    int maxm = 0, maxn = 0, big = 0, direct_ok = 1;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      if (d[i].kind != kind || d[i].M <= 0 || d[i].N <= 0) continue;
+      GXP& P = G.p[G.n++];
+      P.A = {d[i].A, d[i].ra.d, d[i].ra.ld, d[i].ra.inner};
+      P.B = {d[i].B, 1, d[i].ldb, 0};
+      P.C = {d[i].C, d[i].rc.d, d[i].rc.ld, d[i].rc.inner};
+      P.bias = d[i].bias;
+      P.M = d[i].M, P.N = d[i].N, P.K = d[i].K, P.accumulate = d[i].accumulate, P.kind = kind;
+      P.vecA = rows_vec_ok(d[i].A, d[i].ra);
+      P.vecB = aligned16(d[i].B) && d[i].ldb % 4 == 0;
+      if (P.K % 16 != 0 || !P.vecA || (kind == 1 && !P.vecB)) direct_ok = 0;
+      if (eqf_cdiv(P.M, GX_T) > maxm) maxm = eqf_cdiv(P.M, GX_T);
+      if (eqf_cdiv(P.N, GX_T) > maxn) maxn = eqf_cdiv(P.N, GX_T);
+      if (P.M >= 32768 / 2 + 1) big = 1;  // more than 16 k rows: edge rows
+      flops += 2.0 * P.M * (double)P.N * P.K;
+      bytes += 4.0 * ((double)P.M * P.K + (double)P.K * P.N + (double)P.M * P.N);
+    }
+    if (G.n == 0) continue;
+    // few rows (node-level linears): one wave per 32 x 32 tile, whole K chunks in flight; many rows (edge-level: the radial
+    // MLPs): the LDS-tiled kernel.  Timed under different names.
+    const bool direct = !big && direct_ok && !g_gemmx_no_direct;
+    dim3 grid(direct ? 2 * maxm : maxm, direct ? 2 * maxn : maxn, G.n);
+    const int pid = eqf_prof_begin(kind == 0 ? (big ? "gemmx_group_kn_edge" : "gemmx_group_kn_node")
+                                             : (big ? "gemmx_group_nk_edge" : "gemmx_group_nk_node"), st, flops, bytes);
+#define GX_ROWS(M_)                                                                                              \
+  do {                                                                                                           \
+    if (direct) {                                                                                                \
+      if (kind == 0) hipLaunchKernelGGL((gemmx_rows_direct_kernel<M_, 0>), grid, dim3(64), 0, st, G);           \
+      else hipLaunchKernelGGL((gemmx_rows_direct_kernel<M_, 1>), grid, dim3(64), 0, st, G);                     \
+    } else if (kind == 0) hipLaunchKernelGGL((gemmx_rows_kernel<M_, 0>), grid, dim3(256), 0, st, G);            \
+    else hipLaunchKernelGGL((gemmx_rows_kernel<M_, 1>), grid, dim3(256), 0, st, G);                             \
+  } while (0)
+    if (mode == 0) GX_ROWS(0);
+    else if (mode == 1) GX_ROWS(1);
+    else GX_ROWS(2);
+#undef GX_ROWS
+    eqf_prof_end(pid, st);
+    EQF_CHECK_LAUNCH();
+  }
+  {
+    memset(&G, 0, sizeof G);
+    int maxm = 0, maxn = 0, z = 0, big = 0, zd = 0;
+    int zoff_d[GX_MAXP + 1];
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      if (d[i].kind != 2 && d[i].kind != 3) continue;
+      if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0) continue;
+      GXP& P = G.p[G.n];
+      P.A = {d[i].A, d[i].ra.d, d[i].ra.ld, d[i].ra.inner};
+      P.B = {d[i].B, d[i].rc.d, d[i].rc.ld, d[i].rc.inner};
+      P.Cw = d[i].C, P.ldc = d[i].ldb, P.M = d[i].M, P.N = d[i].N, P.K = d[i].K, P.kind = d[i].kind;
+      P.cs = const_cast<float*>(d[i].bias);
+      const int tiles = eqf_cdiv(P.M, GX_T) * eqf_cdiv(P.N, GX_T);
+      const int total_steps = eqf_cdiv(P.K, GX_BK);
+      int ksplit = 1024 / (tiles > 0 ? tiles : 1);
+      const int max_split = eqf_cdiv(total_steps, 8);  // at least 8 steps (256 reduction rows) per workgroup
+      if (ksplit > max_split) ksplit = max_split;
+      if (ksplit < 1) ksplit = 1;
+      P.steps_per_split = eqf_cdiv(total_steps, ksplit);
+      ksplit = eqf_cdiv(total_steps, P.steps_per_split);
+      G.zoff[G.n] = z;
+      z += ksplit;
+      zoff_d[G.n] = zd;
+      zd += eqf_cdiv(P.K, GD_KC);
+      G.n++;
+      if (eqf_cdiv(P.M, GX_T) > maxm) maxm = eqf_cdiv(P.M, GX_T);
+      if (eqf_cdiv(P.N, GX_T) > maxn) maxn = eqf_cdiv(P.N, GX_T);
+      if (P.K >= 32768 / 2 + 1) big = 1;
+      flops += 2.0 * P.M * (double)P.N * P.K;
+      bytes += 4.0 * ((double)P.K * P.M + (double)P.K * P.N + (double)P.M * P.N);
+    }
+    if (G.n > 0) {
+      G.zoff[G.n] = z;
+      const bool direct = !big && !g_gemmx_no_direct;
+      if (direct) {
+        zoff_d[G.n] = zd;
+        for (int i = 0; i <= G.n; ++i) G.zoff[i] = zoff_d[i];
+      }
+      dim3 grid(direct ? 2 * maxm : maxm, direct ? 2 * maxn : maxn, direct ? zd : z);
+      const int pid = eqf_prof_begin(big ? "gemmx_group_tn_edge" : "gemmx_group_tn_node", st, flops, bytes);
+      if (direct) {
+        if (mode == 0) hipLaunchKernelGGL((gemmx_tn_direct_kernel<0>), grid, dim3(64), 0, st, G);
+        else if (mode == 1) hipLaunchKernelGGL((gemmx_tn_direct_kernel<1>), grid, dim3(64), 0, st, G);
+        else hipLaunchKernelGGL((gemmx_tn_direct_kernel<2>), grid, dim3(64), 0, st, G);
+      } else if (mode == 0) hipLaunchKernelGGL((gemmx_tn_kernel<0>), grid, dim3(256), 0, st, G);
+      else if (mode == 1) hipLaunchKernelGGL((gemmx_tn_kernel<1>), grid, dim3(256), 0, st, G);
+      else hipLaunchKernelGGL((gemmx_tn_kernel<2>), grid, dim3(256), 0, st, G);
+      eqf_prof_end(pid, st);
+      EQF_CHECK_LAUNCH();
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

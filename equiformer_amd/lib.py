@@ -70,6 +70,7 @@ SIGNATURES = {
     "eqf_gemm_tn": [c_fp, EqfRows, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp],
     "eqf_gemm_tn_colsum": [c_fp, EqfRows, c_fp, EqfRows, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "eqf_gemm_group": [ctypes.POINTER(EqfGemmDesc), c_int, c_fp],
+    "eqf_gemmx_group": [ctypes.POINTER(EqfGemmDesc), c_int, c_int, c_fp],
     "eqf_colsum": [c_fp, EqfRows, c_int, c_int, c_fp, c_fp],
     "eqf_dtp_coupling_fwd": [c_fp, c_fp, _P_PATHS, c_fp, c_int, c_fp],
     "eqf_dtp_coupling_bwd": [c_fp, c_fp, _P_PATHS, c_fp, c_int, c_fp],

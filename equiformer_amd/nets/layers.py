@@ -531,7 +531,10 @@ class GraphAttention(nn.Module):
     def forward(self, node_input, node_attr=None, edge_src=None, edge_dst=None, edge_attr=None, edge_scalars=None,
                 batch=None, ectx=None, **kwargs):
         g = ectx.graph
-        message = ops.gather_add(self.merge_src(node_input), self.merge_dst(node_input), g)
+        # merge_src / merge_dst read the same rows: their per-degree GEMMs go out side by side in one launch
+        ms, md = ops.irreps_linear_pair(node_input, self.merge_src.tp.weight, self.merge_src._bias(), self.merge_src.spec,
+                                        self.merge_dst.tp.weight, self.merge_dst._bias(), self.merge_dst.spec)
+        message = ops.gather_add(ms, md, g)
         if not self.nonlinear_message:
             value, alpha = self._linear_message(message, ectx)
         else:

@@ -342,12 +342,22 @@ class LinearSpec:
         return l == 0 and out_off == self.bias_out_off
 
 
+# per-degree / dense linears on the bf16 matrix cores (csrc/gemmx.hip) in every matrix mode but "fp32"; the switch exists for
+# A/B measurements (tools/) and cross-checks
+_gemmx = [True]
+
+
 def _gemm_group(descs, st):
-    """One launch per kind for up to 8 GEMMs (eqf_gemm_group)."""
+    """One launch per kind for up to 8 GEMMs: eqf_gemmx_group (split-precision / bf16 planes on the bf16 matrix cores) in the
+    matrix modes split / bf16 / split6, eqf_gemm_group (exact-fp32 MFMA) in the mode fp32."""
+    m = _MATRIX_MODES[_matrix_mode[0]] if _gemmx[0] else None
     for i in range(0, len(descs), 8):
         chunk = descs[i:i + 8]
         arr = (EqfGemmDesc * len(chunk))(*chunk)
-        call("eqf_gemm_group", arr, len(chunk), st)
+        if m is None:
+            call("eqf_gemm_group", arr, len(chunk), st)
+        else:
+            call("eqf_gemmx_group", arr, len(chunk), m, st)
 
 
 def _desc(kind, A, ra, B, ldb, C, rc, bias, M, N, K):
@@ -355,7 +365,8 @@ def _desc(kind, A, ra, B, ldb, C, rc, bias, M, N, K):
                        0, kind)
 
 
-def _lin_fwd(x, weight, bias, spec):
+def _lin_fwd_descs(x, weight, bias, spec):
+    """(output tensor, descriptors of the per-degree GEMMs out_l = x_l W_l (+ bias on 0e))"""
     n = x.shape[0]
     Din, Dout = spec.in_layout.dim, spec.out_layout.dim
     out = (torch.empty if spec.out_covered else torch.zeros)((n, Dout), device=x.device, dtype=torch.float32)
@@ -365,11 +376,16 @@ def _lin_fwd(x, weight, bias, spec):
         b = bias if (spec.has_bias(l, out_off) and bias is not None) else None
         descs.append(_desc(0, (x, in_off), rows(d, Din, K), (weight, w_off), N, (out, out_off), rows(d, Dout, N), b,
                            n * d, N, K))
+    return out, descs
+
+
+def _lin_fwd(x, weight, bias, spec):
+    out, descs = _lin_fwd_descs(x, weight, bias, spec)
     _gemm_group(descs, _stream())
     return out
 
 
-def _lin_dgrad(dy, weight, spec):
+def _lin_dgrad_descs(dy, weight, spec):
     n = dy.shape[0]
     Din, Dout = spec.in_layout.dim, spec.out_layout.dim
     dx = (torch.empty if spec.in_covered else torch.zeros)((n, Din), device=dy.device, dtype=torch.float32)
@@ -378,13 +394,16 @@ def _lin_dgrad(dy, weight, spec):
         d = 2 * l + 1
         descs.append(_desc(1, (dy, out_off), rows(d, Dout, N), (weight, w_off), N, (dx, in_off), rows(d, Din, K), None,
                            n * d, K, N))
+    return dx, descs
+
+
+def _lin_dgrad(dy, weight, spec):
+    dx, descs = _lin_dgrad_descs(dy, weight, spec)
     _gemm_group(descs, _stream())
     return dx
 
 
-def _lin_wgrad(x, dy, spec, dw, db=None):
-    """dw (flat, zero-initialised by the caller) += x^T dy per degree; db (zero-initialised, optional) += the column
-    sums of the scalar block of dy, accumulated by the same launch while dy is staged."""
+def _lin_wgrad_descs(x, dy, spec, dw, db=None):
     n = x.shape[0]
     Din, Dout = spec.in_layout.dim, spec.out_layout.dim
     descs = []
@@ -393,7 +412,13 @@ def _lin_wgrad(x, dy, spec, dw, db=None):
         # kind 2: C[K,N] += sum_rows x[row, 0:K]^T dy[row, 0:N]; "rc" describes the dy rows, ldb = ldc
         descs.append(_desc(2, (x, in_off), rows(d, Din, K), (dy, out_off), N, (dw, w_off), rows(d, Dout, N),
                            db if spec.has_bias(l, out_off) else None, K, N, n * d))
-    _gemm_group(descs, _stream())
+    return descs
+
+
+def _lin_wgrad(x, dy, spec, dw, db=None):
+    """dw (flat, zero-initialised by the caller) += x^T dy per degree; db (zero-initialised, optional) += the column
+    sums of the scalar block of dy, accumulated by the same launch while dy is staged."""
+    _gemm_group(_lin_wgrad_descs(x, dy, spec, dw, db), _stream())
     return dw
 
 
@@ -501,11 +526,93 @@ def irreps_linear(x, weight, bias, spec):
     return _IrrepsLinear.apply(x, weight, bias, spec)
 
 
+class _IrrepsLinearPair(Function):
+    """Two per-degree linears of the SAME input (GraphAttention's merge_src / merge_dst, nets/graph_attention_transformer.py:
+    485-486) with their GEMMs side by side in one launch: forward 1 launch instead of 2, data gradients 1 + one add instead of
+    2 + autograd's add, weight gradients 1 instead of 2 -- these node-row launches cost ~12 us each whatever they compute
+    (tools/gemm_shapes.py).  Under create_graph the backward is the two linears' own differentiable pieces."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, spec1, spec2):
+        x, w1, w2 = _c(x), _c(w1), _c(w2)
+        _chk(x, w1, b1, w2, b2)
+        assert x.shape[1] == spec1.in_layout.dim == spec2.in_layout.dim
+        y1, d1 = _lin_fwd_descs(x, w1, b1, spec1)
+        y2, d2 = _lin_fwd_descs(x, w2, b2, spec2)
+        _gemm_group(d1 + d2, _stream())
+        ctx.save_for_backward(x, w1, w2)
+        ctx.specs = (spec1, spec2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x, w1, w2 = ctx.saved_tensors
+        spec1, spec2 = ctx.specs
+        need = ctx.needs_input_grad  # x, w1, b1, w2, b2
+        ws, specs, dys, hb = (w1, w2), (spec1, spec2), [dy1, dy2], ctx.has_bias
+        for i in (0, 1):
+            if dys[i] is None:
+                dys[i] = _zeros((x.shape[0], specs[i].out_layout.dim), device=x.device, dtype=torch.float32)
+        if torch.is_grad_enabled():  # create_graph: every piece is itself differentiable
+            dx = None
+            if need[0]:
+                dx = _LinDgrad.apply(dys[0], w1, spec1) + _LinDgrad.apply(dys[1], w2, spec2)
+            if not _want_param_grads():
+                return dx, None, None, None, None, None, None
+            out = [dx]
+            for i in (0, 1):
+                out.append(_LinWgrad.apply(x, dys[i], specs[i]) if need[1 + 2 * i] else None)
+                db = None
+                if hb[i] and need[2 + 2 * i]:
+                    o = specs[i].out_layout.offsets[specs[i].out_layout.seg_index(0)]
+                    db = dys[i][:, o:o + specs[i].bias_dim].sum(0)
+                out.append(db)
+            return tuple(out) + (None, None)
+        dys = [_c(d) for d in dys]
+        _chk(*dys)
+        st = _stream()
+        dx = None
+        if need[0]:
+            dxa, da = _lin_dgrad_descs(dys[0], w1, spec1)
+            dxb, db_ = _lin_dgrad_descs(dys[1], w2, spec2)
+            _gemm_group(da + db_, st)
+            dx = dxa.add_(dxb)
+        if not _want_param_grads():
+            return dx, None, None, None, None, None, None
+        grads = [None, None, None, None]  # dw1, db1, dw2, db2
+        descs, late = [], []
+        for i in (0, 1):
+            want_b = hb[i] and need[2 + 2 * i]
+            if not (need[1 + 2 * i] or want_b):
+                continue
+            dw_, dbv = _zeros2(ws[i].numel(), specs[i].bias_dim if want_b else 0, x.device)
+            fused_b = want_b and need[1 + 2 * i] and any(specs[i].has_bias(l, o) and N == specs[i].bias_dim
+                                                         for (l, _, _, o, N, _) in specs[i].pairs)
+            if need[1 + 2 * i]:
+                descs += _lin_wgrad_descs(x, dys[i], specs[i], dw_, dbv if fused_b else None)
+                grads[2 * i] = dw_
+            if want_b:
+                grads[2 * i + 1] = dbv
+                if not fused_b:
+                    late.append((i, dbv))
+        if descs:
+            _gemm_group(descs, st)
+        for i, dbv in late:
+            o = specs[i].out_layout.offsets[specs[i].out_layout.seg_index(0)]
+            call("eqf_colsum", _p(dys[i], o), rows(1, specs[i].out_layout.dim, 0), x.shape[0], specs[i].bias_dim, _p(dbv), st)
+        return dx, grads[0], grads[1], grads[2], grads[3], None, None
+
+
+def irreps_linear_pair(x, w1, b1, spec1, w2, b2, spec2):
+    return _IrrepsLinearPair.apply(x, w1, b1, w2, b2, spec1, spec2)
+
+
 def _dense_fwd(x, weight, bias):
     M, K = x.shape
     N = weight.shape[0]
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-    call("eqf_gemm_nt", _p(x), rows(1, K, 0), _p(weight), K, _p(y), rows(1, N, 0), _p(bias), M, N, K, 0, _stream())
+    _gemm_group([_desc(1, (x, 0), rows(1, K, 0), (weight, 0), K, (y, 0), rows(1, N, 0), bias, M, N, K)], _stream())
     return y
 
 
@@ -513,7 +620,7 @@ def _dense_dgrad(dy, weight):
     M, N = dy.shape
     K = weight.shape[1]
     dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
-    call("eqf_gemm_nn", _p(dy), rows(1, N, 0), _p(weight), K, _p(dx), rows(1, K, 0), None, M, K, N, 0, _stream())
+    _gemm_group([_desc(0, (dy, 0), rows(1, N, 0), (weight, 0), K, (dx, 0), rows(1, K, 0), None, M, K, N)], _stream())
     return dx
 
 
@@ -521,7 +628,7 @@ def _dense_wgrad(x, dy, dw, db=None):
     """dw [N, K] (zero-initialised) += dy^T x; db [N] (zero-initialised, optional) += column sums of dy (same launch)"""
     M, K = x.shape
     N = dy.shape[1]
-    call("eqf_gemm_tn_colsum", _p(dy), rows(1, N, 0), _p(x), rows(1, K, 0), _p(dw), K, N, K, M, _p(db), None, _stream())
+    _gemm_group([_desc(3, (dy, 0), rows(1, N, 0), (x, 0), K, (dw, 0), rows(1, K, 0), db, N, K, M)], _stream())
     return dw
 
 

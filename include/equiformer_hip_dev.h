@@ -39,6 +39,8 @@ int eqf_sfcx_dev_plan(int kind, const eqf_dtp_paths* paths, const eqf_irreps* ou
 /* switches of the split-precision kernels: key 0 = data-gradient kernel (2 = the multi-wave kernel of csrc/sfcx_bwd2.hip where
  * the operator fits it; anything else = the one-wave kernel, the default) */
 int eqf_sfcx_dev_set(int key, int value);
+/* csrc/gemmx.hip: key 0 = 0 selects the one-wave-per-tile kernels for node-row problems (default 1: LDS-tiled kernels for all) */
+int eqf_gemmx_dev_set(int key, int value);
 /* gemm kernels: 1 no stores, 2 no MFMA */
 int eqf_gemm_debug_exp(int mask);
 

@@ -146,11 +146,11 @@ def test_qm9_full_batch_is_deterministic():
         assert torch.equal(y, ys[0]), float((y - ys[0]).abs().max())
 
 
-def test_qm9_full_batch_matches_fp64_oracle():
+def _full_batch_errors(mode):
     """The bench workload itself (reference: nets/graph_attention_transformer.py:864-899 with the model of :921-937,
     L1 loss of engine.py:71) against the oracle in fp64: energies of all 128 molecules and the gradient of every
-    parameter tensor."""
-    from equiformer_amd import nets
+    parameter tensor, in matrix mode `mode`."""
+    from equiformer_amd import nets, ops
     dev = _dev()
     torch.manual_seed(0)
     ref = onets.graph_attention_transformer_nonlinear_l2("5x0e", 5.0).double().eval()
@@ -159,12 +159,11 @@ def test_qm9_full_batch_matches_fp64_oracle():
     mod = mod.to(dev).eval()
     d = _bench_batch()
     yr = ref(None, d["pos"].double(), d["batch"], d["z"])
-    y = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
-    err = _rel(y.cpu(), yr)
-    print("128 molecules: energy rel err vs fp64 oracle %.3e" % err)
-    assert err < 1e-4
     gr = torch.autograd.grad((yr.squeeze() - d["y"].double()).abs().mean(), list(ref.parameters()), allow_unused=True)
-    gg = torch.autograd.grad((y.squeeze() - d["y"].to(dev)).abs().mean(), list(mod.parameters()), allow_unused=True)
+    with ops.matrix_mode(mode):
+        y = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
+        gg = torch.autograd.grad((y.squeeze() - d["y"].to(dev)).abs().mean(), list(mod.parameters()), allow_unused=True)
+    err = _rel(y.cpu(), yr)
     worst = []
     for (n, _), a, r in zip(ref.named_parameters(), gg, gr):
         assert (a is None) == (r is None), n
@@ -172,5 +171,26 @@ def test_qm9_full_batch_matches_fp64_oracle():
             continue
         worst.append((_rel(a.cpu(), r), n))
     worst.sort(reverse=True)
-    print("worst parameter-gradient rel errs:", ["%s %.2e" % (n, e) for e, n in worst[:5]])
+    print("128 molecules, matrix mode %s: energy rel err vs fp64 oracle %.3e; worst parameter-gradient rel errs: %s"
+          % (mode, err, ["%s %.2e" % (n, e) for e, n in worst[:5]]))
+    return err, worst
+
+
+def test_qm9_full_batch_matches_fp64_oracle():
+    """default arithmetic (split: every matrix step -- fused SeparableFCTP, per-degree linears, radial MLPs -- multiplies fp32
+    operands as bf16 planes on the bf16 matrix cores): the north-star bar, 1e-4 relative"""
+    err, worst = _full_batch_errors("split")
+    assert err < 1e-4
     assert worst[0][0] < 1e-4, worst[:5]
+
+
+def test_qm9_full_batch_bf16_mode_stated_tolerance():
+    """BASELINE config #2 at the bench batch: EVERY matrix step (fused SeparableFCTP, per-degree linears, radial MLPs) takes plain
+    bf16 operands with fp32 accumulation; storage, layer norm, softmax, radial basis, gate stay fp32 -- the arithmetic of the
+    reference's AMP default (autocast of every linear, main_qm9.py:117-119,197-201; layer norm pinned to fp32,
+    nets/layer_norm.py:89).  Stated tolerance: energies 2e-2, parameter gradients 1e-1 of the gradient's scale (CPU emulation of
+    one-plane arithmetic, tools/split_model_error.py: 4.4e-3 / 2.2e-2; the measured values are printed)."""
+    err, worst = _full_batch_errors("bf16")
+    assert err < 2e-2
+    assert worst[0][0] < 1e-1, worst[:5]
+
