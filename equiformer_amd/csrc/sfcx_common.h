@@ -97,7 +97,7 @@ __device__ __forceinline__ void stage_m(float* __restrict__ Mt, const int MS, co
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       const int e = min(e0 + 2 * p + hi, elast);
-      v[p] = cp[(size_t)e * m_ld + jc];
+      v[p] = cp[(unsigned)e * m_ld + (unsigned)jc];  // 32-bit element offset (fits32): one base pointer, no 64-bit address pairs
     }
     if (jv) {
 #pragma unroll
