@@ -165,8 +165,14 @@ def version():
     return load().eqf_version().decode()
 
 
+_fn_cache = {}
+
+
 def call(name, *args):
-    rc = getattr(load(), name)(*args)
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
         raise HipLibraryError("%s failed with code %d" % (name, rc))
 
