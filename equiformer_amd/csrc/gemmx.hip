@@ -34,7 +34,7 @@ constexpr int GX_BK = 32;
 constexpr int GX_LDK = 40;       // bf16 elements per LDS row: 32 + 8 (80 bytes)
 constexpr int GX_T = 64;         // tile edge (rows and columns)
 constexpr int GX_ROW = GX_T * GX_LDK;
-constexpr int GX_MAXP = 8;
+constexpr int GX_MAXP = 24;     // problems per launch (the argument block stays under the 4 KB kernarg limit)
 
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
@@ -54,6 +54,7 @@ struct GXP {          // one problem
   int vecA, vecB;
   int steps_per_split;
 };
+static_assert(sizeof(GXP) * GX_MAXP + 4 * (GX_MAXP + 2) <= 4000, "kernarg segment");
 struct GXGroup {
   int n;
   int zoff[GX_MAXP + 1];  // tn: blockIdx.z -> (problem, split)

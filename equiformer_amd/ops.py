@@ -362,8 +362,9 @@ def _gemm_group(descs, st):
     """One launch per kind for up to 8 GEMMs: eqf_gemmx_group (split-precision / bf16 planes on the bf16 matrix cores) in the
     matrix modes split / bf16 / split6, eqf_gemm_group (exact-fp32 MFMA) in the mode fp32."""
     m = _MATRIX_MODES[_matrix_mode[0]] if _gemmx[0] else None
-    for i in range(0, len(descs), 8):
-        chunk = descs[i:i + 8]
+    step = 8 if m is None else 24
+    for i in range(0, len(descs), step):
+        chunk = descs[i:i + step]
         arr = (EqfGemmDesc * len(chunk))(*chunk)
         if m is None:
             call("eqf_gemm_group", arr, len(chunk), st)
@@ -424,6 +425,69 @@ def _lin_wgrad_descs(x, dy, spec, dw, db=None):
         descs.append(_desc(2, (x, in_off), rows(d, Din, K), (dy, out_off), N, (dw, w_off), rows(d, Dout, N),
                            db if spec.has_bias(l, out_off) else None, K, N, n * d))
     return descs
+
+
+# Weight gradients of the node-row linears are not on backward's dependency chain: dW = x^T dy needs nothing that comes later
+# and nothing later needs dW.  Each of these launches costs 16-24 us whatever it computes (2 304 rows; profiles/r04), so in a
+# plain (first-order) backward the ones that belong to LEAF parameters are queued and go out TOGETHER when the autograd engine
+# finishes the pass (engine callback) -- 27 launches of 3 problems become 4 launches of <= 24.  backward() returns
+# zero-initialised tensors as the gradients; AccumulateGrad makes them (or adds them to) the parameter's .grad, and the deferred
+# launch accumulates into whatever tensor the parameter's .grad IS when the pass ends.  Off while a data-parallel reducer ships
+# gradients from a backward hook (they would not be there yet): FlatGradAllReduce switches it off.
+_defer_wgrad = [True]
+_deferred = []
+
+
+def set_deferred_weight_gradients(on):
+    prev = _defer_wgrad[0]
+    _defer_wgrad[0] = bool(on)
+    return prev
+
+
+def _alias(t):
+    """(storage, offset, numel) of a tensor: keeps the MEMORY alive without holding the tensor object (AccumulateGrad only adopts
+    a gradient tensor nobody else references)"""
+    return (t.untyped_storage(), t.storage_offset(), t.numel(), t.device)
+
+
+def _from_alias(a):
+    stor, off, n, dev = a
+    return torch.empty(0, dtype=torch.float32, device=dev).set_(stor, off, (n,))
+
+
+def _flush_wgrads():
+    entries = list(_deferred)
+    del _deferred[:]
+    descs = []
+    for (w, b, x, dy, spec, fused_b, aw, ab) in entries:
+        # where the gradient lives now: the zero tensor backward() returned -- adopted as .grad by AccumulateGrad, or captured
+        # by torch.autograd.grad (.grad still None) -- unless AccumulateGrad made a copy of it (then .grad is another tensor)
+        tw = _from_alias(aw)
+        if w.grad is not None and w.grad.data_ptr() != tw.data_ptr():
+            tw = w.grad.view(-1)
+        tb = None
+        if fused_b:
+            tb = _from_alias(ab)
+            if b.grad is not None and b.grad.data_ptr() != tb.data_ptr():
+                tb = b.grad.view(-1)
+        if not tw.is_contiguous() or tw.dtype != torch.float32 or (tb is not None and not tb.is_contiguous()):
+            raise RuntimeError("deferred weight gradient: .grad must be a contiguous fp32 tensor")
+        descs += _lin_wgrad_descs(x, dy, spec, tw, tb)
+    if descs:
+        _gemm_group(descs, _stream())
+
+
+def _can_defer(*params):
+    """plain first-order backward, leaf parameters without an existing .grad (an existing one is added to OUT of place or in
+    place depending on the engine's mood: those gradients are computed at once)"""
+    return (_defer_wgrad[0] and not torch.is_grad_enabled()
+            and all(p is None or (p.is_leaf and p.requires_grad and p.grad is None) for p in params))
+
+
+def _defer_lin_wgrad(w, b, x, dy, spec, fused_b, dw, db):
+    if not _deferred:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+    _deferred.append((w, b, x, dy, spec, fused_b, _alias(dw), _alias(db) if fused_b else None))
 
 
 def _lin_wgrad(x, dy, spec, dw, db=None):
@@ -491,6 +555,7 @@ class _IrrepsLinear(Function):
         ctx.save_for_backward(x, weight)
         ctx.spec = spec
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias if (bias is not None and bias.is_leaf) else None  # (identity only: for the deferred gradients)
         return out
 
     @staticmethod
@@ -524,7 +589,12 @@ class _IrrepsLinear(Function):
         fused_b = want_b and ctx.needs_input_grad[1] and any(spec.has_bias(l, o) and N == spec.bias_dim
                                                               for (l, _, _, o, N, _) in spec.pairs)
         if ctx.needs_input_grad[1]:
-            dw = _lin_wgrad(x, dy, spec, dw_, db_ if fused_b else None)
+            bp = ctx.bias_param if fused_b else None
+            if _can_defer(weight, bp) and (not fused_b or bp is not None):
+                _defer_lin_wgrad(weight, bp, x, dy, spec, fused_b, dw_, db_)  # (zeros now) filled when backward ends
+                dw = dw_
+            else:
+                dw = _lin_wgrad(x, dy, spec, dw_, db_ if fused_b else None)
         if want_b:
             db = db_
             if not fused_b:
@@ -554,6 +624,7 @@ class _IrrepsLinearPair(Function):
         ctx.save_for_backward(x, w1, w2)
         ctx.specs = (spec1, spec2)
         ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.bias_params = tuple(b if (b is not None and b.is_leaf) else None for b in (b1, b2))
         return y1, y2
 
     @staticmethod
@@ -601,7 +672,11 @@ class _IrrepsLinearPair(Function):
             fused_b = want_b and need[1 + 2 * i] and any(specs[i].has_bias(l, o) and N == specs[i].bias_dim
                                                          for (l, _, _, o, N, _) in specs[i].pairs)
             if need[1 + 2 * i]:
-                descs += _lin_wgrad_descs(x, dys[i], specs[i], dw_, dbv if fused_b else None)
+                bp = ctx.bias_params[i] if fused_b else None
+                if _can_defer(ws[i], bp) and (not fused_b or bp is not None):
+                    _defer_lin_wgrad(ws[i], bp, x, dys[i], specs[i], fused_b, dw_, dbv)
+                else:
+                    descs += _lin_wgrad_descs(x, dys[i], specs[i], dw_, dbv if fused_b else None)
                 grads[2 * i] = dw_
             if want_b:
                 grads[2 * i + 1] = dbv

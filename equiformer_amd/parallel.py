@@ -68,6 +68,11 @@ class FlatGradAllReduce:
             k = min(max(k, 1), len(self.params) - 1)
             self.split = k
             self._handles = [p.register_post_accumulate_grad_hook(self._on_tail_grad) for p in self.params[k:]]
+            if self._active():
+                # the hook ships gradients as soon as autograd has accumulated them: weight gradients that are only queued at
+                # that point (equiformer_amd.ops: deferred grouped launches of the node-row linears) must not exist then
+                from . import ops as _ops
+                _ops.set_deferred_weight_gradients(False)
 
     # ---------------------------------------------------------------------------------------------------------------
     def world_size(self):

@@ -206,7 +206,7 @@ int eqf_gemm_group(const eqf_gemm_desc* d, int n, void* stream);
  * planes where they are staged -- mode 0 (split): activations 2 planes, weights 3, 5 products (weight gradients: 2 + 2 planes,
  * 3 products), fp32-class results; mode 1 (bf16): plain bf16 operands, fp32 accumulation (the arithmetic of the reference's
  * AMP linears, main_qm9.py:117-119, engine.py:58-66); mode 2: 3 + 3 planes.  Same descriptors, same results up to the
- * mode's rounding.  [ref: as eqf_gemm_group] */
+ * mode's rounding; up to 24 problems per call (eqf_gemm_group: 8).  [ref: as eqf_gemm_group] */
 int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream);
 
 /* out[n] += sum_rows x[row, n]  over a two-level-row matrix (bias gradients). */

@@ -152,3 +152,46 @@ def test_one_wave_per_tile_kernels_match_the_tiled_ones():
             _lib.load().eqf_gemmx_dev_set(0, 1)
     for a, b in zip(res[0], res[1]):
         assert _rel(a, b) < 2e-6
+
+
+def test_deferred_weight_gradients_equal_immediate_ones():
+    """The weight gradients of node-row linears that belong to leaf parameters are queued during a first-order backward and
+    launched together when the pass ends (ops._defer_lin_wgrad): same values through .backward() (AccumulateGrad adopts the
+    zero tensor the launch later fills), through torch.autograd.grad (captured tensors), and with a pre-existing .grad
+    (not deferred)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as mg
+    from weights import fill_deterministic
+    from equiformer_amd.nets.graph_attention_transformer import GraphAttentionTransformer
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = _dev()
+    m = GraphAttentionTransformer(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **dict(mg.SMALL_L2, alpha_drop=0.0))
+    m = fill_deterministic(m, 21).to(dev).train()
+    d = {k: v.to(dev) for k, v in qm9_like_batch(4, 10, side=5.0, seed=5).items()}
+    params = [p for p in m.parameters() if p.requires_grad]
+
+    def loss():
+        return (m(None, d["pos"], d["batch"], d["z"]).squeeze() - d["y"]).abs().mean()
+
+    res = {}
+    for on in (False, True):
+        prev = ops.set_deferred_weight_gradients(on)
+        try:
+            for p in params:
+                p.grad = None
+            loss().backward()
+            res[on, "backward"] = [None if p.grad is None else p.grad.clone() for p in params]
+            res[on, "grad"] = list(torch.autograd.grad(loss(), params, allow_unused=True))
+            loss().backward()  # second pass onto existing .grad: 2 x the gradient
+            res[on, "twice"] = [None if p.grad is None else p.grad.clone() for p in params]
+        finally:
+            ops.set_deferred_weight_gradients(prev)
+    assert not ops._deferred
+    for key in ("backward", "grad", "twice"):
+        for a, b in zip(res[True, key], res[False, key]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert _rel(a, b) < 2e-6, key
+    for a, b in zip(res[True, "twice"], res[True, "backward"]):
+        if a is not None:
+            assert _rel(a, 2.0 * b) < 2e-6

@@ -151,8 +151,10 @@ def test_oc20_e3_auxiliary_head_emits_1o_like_the_reference(rnets):
     r = RefOC20(None, None, 1, use_pbc=True, otf_graph=False, **cfg)
     o = onets.GraphAttentionTransformerOC20(**cfg)
     mrg.copy_by_name(r, o)
-    with pytest.raises(NotImplementedError):  # the product refuses this (unshipped) combination, see its constructor
-        ProdOC20(None, None, 1, use_pbc=True, otf_graph=False, **cfg)
+    # the product builds it too since round 4 (values against the oracle on the GPU: tests/test_gpu_oc20_heads.py): same
+    # parameter names, shapes and order as the reference
+    prod = ProdOC20(None, None, 1, use_pbc=True, otf_graph=False, **cfg)
+    assert [(n, tuple(p.shape)) for n, p in prod.named_parameters()] == [(n, tuple(p.shape)) for n, p in r.named_parameters()]
     r, o = mrg.as_double(r), o.double().eval()
     ins, _ = mrg.load_fixture("oc20_aux_small")
     t = torch.as_tensor
