@@ -241,6 +241,42 @@ inline SfcOrder xcd_order(int nx, int ny, int& nblocks) {
   return o;
 }
 
+// Gated input rows (the consumer side of Gate, nets/fast_activation.py:132-148): the operator's input x is NOT materialised;
+// the kernels read the gate's INPUT rows [scalars (S) | gates (G) | gated segments] and apply c_silu * silu to the scalar
+// segment and c_sig * sigmoid(gate of the channel) to the l > 0 segments where they load x, and the data gradient writes the
+// gradient of those raw rows (the gate's backward, complete inside a 32-channel slab: every gate scalar belongs to one slab).
+struct XGate {
+  int on, S, G;
+  float c_silu, c_sig;
+};
+__device__ __forceinline__ float xg_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// offsets of an input segment (offset in_off, multiplicity mul in the operator's input row = the gate's OUTPUT row) inside the
+// raw row: raw_off = its data, g_off = its gate scalars (-1: the scalar segment, activated; -2: no gating)
+inline int gate_map(const XGate& gt, const eqf_dtp_paths* P, int in_off, int mul, int d1, int& raw_off, int& g_off) {
+  raw_off = in_off, g_off = -2;
+  if (!gt.on) return 0;
+  if (in_off == 0) {
+    if (d1 != 1 || mul != gt.S) return EQF_E_UNSUPPORTED;
+    g_off = -1;
+    return 0;
+  }
+  if (d1 == 1 || in_off < gt.S) return EQF_E_UNSUPPORTED;  // a second scalar segment / E(3) rows: not gated layouts
+  int before = 0, seen[EQF_MAX_SEG], ns = 0;
+  for (int p = 0; p < P->npaths; ++p) {
+    const int o = P->in_off[p];
+    if (o <= 0 || o >= in_off) continue;
+    bool dup = false;
+    for (int k = 0; k < ns; ++k) dup |= seen[k] == o;
+    if (dup) continue;
+    if (ns >= EQF_MAX_SEG) return EQF_E_UNSUPPORTED;
+    seen[ns++] = o;
+    before += P->mul[p];
+  }
+  raw_off = in_off + gt.G;
+  g_off = gt.S + before;
+  return 0;
+}
+
 constexpr int XB_MAXGRP = 12;
 constexpr int XB_MAXPATH = 12;
 struct XBPath {
@@ -250,7 +286,8 @@ struct XBPath {
   int m_off;        // offset of the path's matrix in the coupling row
 };
 struct XBGroup {
-  int x_off;  // offset of the slab (segment + 32 c) in the x row
+  int x_off;  // offset of the slab (segment + 32 c) in the x row (the raw row when the input is gated)
+  int g_off;  // gated input: offset of the slab's 32 gate scalars in the raw row (-1 scalar segment, -2 plain input)
   short mul, d1, npath, pad;
   XBPath p[XB_MAXPATH];
 };
@@ -262,6 +299,7 @@ struct XBwdArgs {
   float *dx, *dw, *dM;
   const __bf16* packed;
   int ms;
+  XGate gate;
   SfcOrder ord;  // nx = edge tiles, ny = groups of this launch
   struct Deg {
     int d3, N1, Ncat, out1_off, nt;
@@ -288,15 +326,18 @@ inline int max_deg(const SfcCommon& C) {
   return md;
 }
 
-inline int plan_bwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XBwdArgs& A, int& nblk, size_t& lds, int& ngrp_out) {
+inline int plan_bwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XBwdArgs& A, int& nblk, size_t& lds, int& ngrp_out,
+                    const XGate* gate = nullptr) {
   if (!fits32(C)) return EQF_E_UNSUPPORTED;
   if (max_deg(C) > 7) return EQF_E_UNSUPPORTED;
+  if (gate && gate->on && max_deg(C) > 5) return EQF_E_UNSUPPORTED;  // (the half-pass items of degree-3 models are not gated)
   PkDeg pk[SFC_MAX_DEG];
   pack_layout(C, mode_npw(mode), pk);
   memset(&A, 0, sizeof A);
   A.x = C.x, A.coupling = C.coupling, A.w = C.w;
   A.x_ld = C.x_ld, A.m_ld = C.m_ld, A.w_ld = C.w_ld, A.E = C.E;
   A.d1 = C.o1, A.d2 = C.o2, A.ld1 = C.ld1, A.ld2 = C.ld2;
+  if (gate) A.gate = *gate;
   for (int d = 0; d < C.ndeg; ++d) {
     const SfcDeg& D = C.deg[d];
     A.deg[d].d3 = D.d3, A.deg[d].N1 = D.N1, A.deg[d].Ncat = D.Ncat, A.deg[d].out1_off = D.out1_off;
@@ -316,7 +357,10 @@ inline int plan_bwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XBwdAr
     for (int c = 0; c < mul; c += 32) {
       if (ngrp >= XB_MAXGRP) return EQF_E_UNSUPPORTED;
       XBGroup& G = A.grp[ngrp];
-      G.x_off = P->in_off[p] + c, G.mul = (short)mul, G.d1 = (short)d1, G.npath = 0;
+      int raw_off = 0, g_off = -2;
+      const int grc = gate_map(A.gate, P, P->in_off[p], mul, d1, raw_off, g_off);
+      if (grc) return grc;
+      G.x_off = raw_off + c, G.g_off = g_off >= 0 ? g_off + c : g_off, G.mul = (short)mul, G.d1 = (short)d1, G.npath = 0;
       for (int d = 0; d < C.ndeg; ++d)
         for (int q = 0; q < P->npaths; ++q) {
           if (P->in_off[q] != P->in_off[p] || P->l3[q] != C.deg[d].l3) continue;

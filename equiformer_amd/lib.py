@@ -30,6 +30,10 @@ class EqfGemmDesc(ctypes.Structure):
                 ("ldb", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("accumulate", c_int), ("kind", c_int)]
 
 
+class EqfGateIn(ctypes.Structure):
+    _fields_ = [("S", c_int), ("G", c_int), ("c_silu", ctypes.c_float), ("c_sig", ctypes.c_float)]
+
+
 _PA = c_int * EQF_MAX_PATHS
 
 
@@ -81,6 +85,11 @@ SIGNATURES = {
     "eqf_sfc_bwd_weight": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, c_fp, c_int, _PP, c_fp, c_int, c_fp],
     "eqf_sfcx_packed_numel": [_P_PATHS, _P_IRR, c_int, c_int],
     "eqf_sfcx_supported": [_P_PATHS, _P_IRR, c_int, c_int],
+    "eqf_sfcx_fwd_gated": [c_fp, ctypes.POINTER(EqfGateIn), c_fp, c_fp, _P_PATHS, c_fp, c_fp, c_fp, _P_IRR, c_int, c_int, c_fp],
+    "eqf_sfcx_bwd_data_gated": [c_fp, ctypes.POINTER(EqfGateIn), c_fp, c_fp, _P_PATHS, c_fp, c_fp, _P_IRR, c_fp, c_fp, c_fp,
+                                c_int, c_int, c_fp],
+    "eqf_sfcx_bwd_weight_gated": [c_fp, ctypes.POINTER(EqfGateIn), c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, _PP, c_int, c_int,
+                                  c_fp],
     "eqf_sfcx_pack": [_PP, c_fp, _P_PATHS, _P_IRR, c_int, c_int, c_fp, c_fp],
     "eqf_sfcx_fwd": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, c_fp, c_fp, _P_IRR, c_fp, c_int, c_int, c_int, c_fp],
     "eqf_sfcx_bwd_data": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, _P_IRR, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp],

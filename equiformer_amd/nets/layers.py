@@ -568,8 +568,16 @@ class GraphAttention(nn.Module):
             mid = ops.dtp(message, M, weight, table)
             alpha = self.sep_alpha(mid)
             value = sa.lin(mid)
-        value = sa.gate(value)
-        value = self.sep_value(value, ectx, use_fused=self.use_fused)
+        sv = self.sep_value
+        gt = sa.gate
+        if (self.use_fused is True and isinstance(gt, Gate) and sv.gate is None
+                and ops.sep_fctp_gated_ok(sv.sfc_spec, value.shape[1], gt.S, gt.gated_layout)):
+            # the gate is folded into sep_value's kernels: its output rows are never written (csrc/sfcx.hip, *_gated)
+            w2 = ectx.radial(sv.dtp_rad) if sv.dtp_rad is not None else None
+            value = ops.sep_fctp_gated(value, ectx.coupling(sv.dtp.table), w2, sv.flat_weight(), sv.lin._bias(), sv.sfc_spec,
+                                       (gt.S, gt.gated_layout, so3.C_SILU, so3.C_SIGMOID))
+        else:
+            value = sv(gt(value), ectx, use_fused=self.use_fused)
         return value, alpha
 
     def _linear_message(self, message, ectx):

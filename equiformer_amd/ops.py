@@ -6,6 +6,7 @@ The operators are the closed primitive set of SURVEY.md Appendix B; `equiformer_
 reference's module tree.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -428,14 +429,28 @@ def _lin_wgrad_descs(x, dy, spec, dw, db=None):
 
 
 # Weight gradients of the node-row linears are not on backward's dependency chain: dW = x^T dy needs nothing that comes later
-# and nothing later needs dW.  Each of these launches costs 16-24 us whatever it computes (2 304 rows; profiles/r04), so in a
-# plain (first-order) backward the ones that belong to LEAF parameters are queued and go out TOGETHER when the autograd engine
-# finishes the pass (engine callback) -- 27 launches of 3 problems become 4 launches of <= 24.  backward() returns
-# zero-initialised tensors as the gradients; AccumulateGrad makes them (or adds them to) the parameter's .grad, and the deferred
-# launch accumulates into whatever tensor the parameter's .grad IS when the pass ends.  Off while a data-parallel reducer ships
-# gradients from a backward hook (they would not be there yet): FlatGradAllReduce switches it off.
-_defer_wgrad = [True]
+# and nothing later needs dW.  Each of these launches costs 16-24 us whatever it computes (2 304 rows; profiles/r04), so a
+# training loop can ask for them to be queued during loss.backward() and launched TOGETHER when the autograd engine finishes the
+# pass (engine callback): 27 launches of 3 problems become 4 launches of <= 24.
+#
+#   ops.set_deferred_weight_gradients(True)        # OPT-IN (bench.py does)
+#
+# backward() then returns zero-initialised tensors as the gradients of LEAF parameters; AccumulateGrad makes them (or a sum
+# containing them) the parameter's .grad, and the deferred launch accumulates into whatever tensor the parameter's .grad IS when
+# the pass ends -- correct for loss.backward() in every case (one or several contributions per parameter, existing .grad).
+# With torch.autograd.grad(loss, parameters) the engine hands the zero tensor back instead of storing it; the launch still
+# lands in it as long as the parameter has ONE contribution in the pass, but a second contribution makes the engine sum
+# out of place and the queued one would be lost -- which is why this is opt-in, why it switches itself off for good once a
+# create_graph pass has been seen in the process (force-loss training gives every parameter several contributions), and why
+# FlatGradAllReduce switches it off (its backward hook ships gradients as soon as autograd has accumulated them).
+_defer_wgrad = [os.environ.get("EQF_DEFER_WGRAD", "") == "1"]
+_seen_create_graph = [False]
 _deferred = []
+
+
+def note_create_graph():
+    """called by the create_graph branches of the operators' backward"""
+    _seen_create_graph[0] = True
 
 
 def set_deferred_weight_gradients(on):
@@ -480,7 +495,7 @@ def _flush_wgrads():
 def _can_defer(*params):
     """plain first-order backward, leaf parameters without an existing .grad (an existing one is added to OUT of place or in
     place depending on the engine's mood: those gradients are computed at once)"""
-    return (_defer_wgrad[0] and not torch.is_grad_enabled()
+    return (_defer_wgrad[0] and not _seen_create_graph[0] and not torch.is_grad_enabled()
             and all(p is None or (p.is_leaf and p.requires_grad and p.grad is None) for p in params))
 
 
@@ -564,6 +579,7 @@ class _IrrepsLinear(Function):
         spec = ctx.spec
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if torch.is_grad_enabled():  # create_graph: every piece is itself differentiable
+            note_create_graph()
             dx = _LinDgrad.apply(dy, weight, spec) if ctx.needs_input_grad[0] else None
             if not _want_param_grads():
                 return dx, None, None, None
@@ -637,6 +653,7 @@ class _IrrepsLinearPair(Function):
             if dys[i] is None:
                 dys[i] = _zeros((x.shape[0], specs[i].out_layout.dim), device=x.device, dtype=torch.float32)
         if torch.is_grad_enabled():  # create_graph: every piece is itself differentiable
+            note_create_graph()
             dx = None
             if need[0]:
                 dx = _LinDgrad.apply(dys[0], w1, spec1) + _LinDgrad.apply(dys[1], w2, spec2)
@@ -2049,6 +2066,7 @@ class _SepFctp(Function):
         st = _stream()
         dev = x.device
         if torch.is_grad_enabled():  # create_graph: differentiable data-gradient (forces); see _SepFctpBwdData
+            note_create_graph()
             need = ctx.needs_input_grad
             if d1 is None:
                 d1 = _zeros((E, spec.out_layout.dim), device=dev, dtype=torch.float32)
@@ -2123,6 +2141,111 @@ class _SepFctp(Function):
                 dbias2 = flat[o3:]
                 call("eqf_colsum", _p(d2), rows(1, spec.n2, 0), E, spec.n2, _p(dbias2), st)
         return dx, dM, dw, dweight, dbias, dweight2, dbias2, None
+
+
+class _SepFctpGated(Function):
+    """Gate -> fused SeparableFCTP with the gate folded into the three split-precision kernels (eqf_sfcx_*_gated): `x_raw` is
+    the gate's INPUT [scalars (S) | gates (G) | gated segments]; the gated rows [E, S + dim(gated)] are never written and
+    the data gradient returns d x_raw (the gate's backward included).  GraphAttention: value = sep_value(sep_act.gate(...))
+    [ref: nets/graph_attention_transformer.py:494-496; Gate: nets/fast_activation.py:132-148].  No second consumer.
+    Under create_graph the backward is composed from the separate differentiable operators (gate, _SepFctpBwdData)."""
+
+    @staticmethod
+    def forward(ctx, x_raw, coupling, w, weight, bias, spec, gate):
+        x_raw, coupling, weight = _c(x_raw), _c(coupling), _c(weight)
+        w = _c(w) if w is not None else None
+        _chk(x_raw, coupling, w, weight, bias)
+        S, gated_layout, c_silu, c_sig = gate
+        G = sum(m for m, _ in gated_layout.segs)
+        assert spec.n2 == 0 and x_raw.shape[1] == S + G + gated_layout.dim and weight.numel() == spec.weight_numel
+        mode = _sfc_mode(spec)
+        assert mode is not None and spec.x_mask(mode) == 7
+        ctx.mode, ctx.gate = mode, gate
+        ctx.gin = lib.EqfGateIn(int(S), int(G), float(c_silu), float(c_sig))
+        ctx.packed = _sfc_pack(weight, None, spec, mode)
+        E = x_raw.shape[0]
+        out = torch.empty((E, spec.out_layout.dim), device=x_raw.device, dtype=torch.float32)
+        call("eqf_sfcx_fwd_gated", _p(x_raw), ctypes.byref(ctx.gin), _p(coupling), _p(w), spec.table.c_ref,
+             ctypes.c_void_p(ctx.packed.data_ptr()), _p(bias), _p(out), spec.out_layout.c_ref, E, mode, _stream())
+        ctx.save_for_backward(x_raw, coupling, w, weight)
+        ctx.spec = spec
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, d1):
+        x_raw, coupling, w, weight = ctx.saved_tensors
+        spec, mode = ctx.spec, ctx.mode
+        S, gated_layout, c_silu, c_sig = ctx.gate
+        need = ctx.needs_input_grad  # x_raw, coupling, w, weight, bias
+        E = x_raw.shape[0]
+        dev = x_raw.device
+        if torch.is_grad_enabled():  # create_graph: the separate differentiable operators, on the re-materialised gate output
+            note_create_graph()
+            xg = gate(x_raw, S, gated_layout, c_silu, c_sig)
+            outs = _SepFctpBwdData.apply(xg, coupling, w, weight, None, d1, None, spec, mode)
+            dxg, dM = outs[0], outs[1]
+            dw = outs[2] if w is not None else None
+            dx_raw = _GateBwd.apply(x_raw, dxg, S, gated_layout, c_silu, c_sig) if need[0] else None
+            gW = gb = None
+            if not _want_param_grads():
+                return dx_raw, dM, dw, None, None, None, None
+            if need[3]:
+                with torch.no_grad():
+                    gW_ = _zeros_like(weight)
+                    _sfc_bwd_weight(xg.detach(), coupling, w, _c(d1), None, spec, gW_, None, mode)
+                gW = _guard(gW_, d1, "weight gradient of the fused SeparableFCTP")
+            if ctx.has_bias and need[4]:
+                o = spec.out_layout.offsets[spec.out_layout.seg_index(0)]
+                gb = d1[:, o:o + spec.out_layout.mul_of(0)].sum(0)
+            return dx_raw, dM, dw, gW, gb, None, None
+        d1 = _c(d1)
+        _chk(d1)
+        st = _stream()
+        dx_raw = dM = dw = dweight = dbias = None
+        if need[0] or need[1] or (w is not None and need[2]):
+            dx_raw = torch.empty_like(x_raw)
+            dw = torch.empty_like(w) if w is not None else None
+            dM = _zeros_like(coupling) if need[1] else None
+            call("eqf_sfcx_bwd_data_gated", _p(x_raw), ctypes.byref(ctx.gin), _p(coupling), _p(w), spec.table.c_ref,
+                 ctypes.c_void_p(ctx.packed.data_ptr()), _p(d1), spec.out_layout.c_ref, _p(dx_raw), _p(dw), _p(dM), E, mode, st)
+        if not _want_param_grads():
+            return dx_raw, dM, dw, None, None, None, None
+        want_b = ctx.has_bias and need[4]
+        if need[3] or want_b:
+            n1_0 = spec.out_layout.mul_of(0)
+            flat = _zeros(spec.weight_numel + (n1_0 if want_b else 0), device=dev, dtype=torch.float32)
+            dweight = flat[:spec.weight_numel]
+            if need[3]:
+                call("eqf_sfcx_bwd_weight_gated", _p(x_raw), ctypes.byref(ctx.gin), _p(coupling), _p(w), spec.table.c_ref,
+                     _p(d1), spec.out_layout.c_ref, _sfc_Wl(dweight, spec), E, mode, st)
+            if want_b:
+                dbias = flat[spec.weight_numel:]
+                o = spec.out_layout.offsets[spec.out_layout.seg_index(0)]
+                call("eqf_colsum", _p(d1, o), rows(1, spec.out_layout.dim, 0), E, n1_0, _p(dbias), st)
+        return dx_raw, dM, dw, (dweight if need[3] else None), dbias, None, None
+
+
+_fuse_gate = [os.environ.get("EQF_NO_GATE_FUSION", "") == ""]  # A/B switch: False = separate gate kernels in front of sep_value
+
+
+def sep_fctp_gated_ok(spec, x_raw_dim, S, gated_layout):
+    """the gate can be folded into this operator's kernels: split-precision kernels for all three launches, no second consumer,
+    degrees <= 2, scalar segment = the first S channels"""
+    if not _fuse_gate[0] or spec.n2 != 0 or not spec.supported:
+        return False
+    mode = _sfc_mode(spec)
+    if mode is None or spec.x_mask(mode) != 7:
+        return False
+    if max([p["l1"] for p in spec.table.paths] + [l3 for l3, _, _, _ in spec.degs]) > 2:
+        return False
+    li = spec.table.layout_in
+    return li.segs[0] == (S, 0) and S % 32 == 0 and li.dim == S + gated_layout.dim
+
+
+def sep_fctp_gated(x_raw, coupling, w, weight, bias, spec, gate):
+    """gate = (S, gated_layout, c_silu, c_sig)"""
+    return _SepFctpGated.apply(x_raw, coupling, w, weight, bias, spec, gate)
 
 
 def sep_fctp(x, coupling, w, weight, bias, spec, weight2=None, bias2=None):

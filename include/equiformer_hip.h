@@ -291,6 +291,29 @@ int eqf_sfcx_bwd_weight(const float* x, const float* coupling, const float* w, c
                         const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2, int n2,
                         float* const* dWl, float* dW2, int E, int mode, void* stream);
 
+/* The same three kernels with the Gate in front of the operator folded into them (GraphAttention: value = sep_value(
+ * sep_act.gate(sep_act.lin(...))), nets/graph_attention_transformer.py:494-496 with the Gate of nets/fast_activation.py:
+ * 132-148): `x_raw` holds the GATE'S INPUT rows [scalars (S) | gates (G) | gated segments], S + G + dim(gated) floats each,
+ * and the operator's input row (the gate's output [scalars | gated segments], which `paths` describes) is never written:
+ * every kernel applies c_silu * silu to the scalar segment and c_sig * sigmoid(gate of the channel) to the l > 0 segments
+ * where it loads x, and the data gradient returns d_x_raw -- the gradient of the raw rows, i.e. the gate's backward as well
+ * (scalars, gates and gated parts; every element written once).  Operators without a second consumer (n2 = 0); degrees <= 2.
+ * EQF_E_UNSUPPORTED otherwise: run eqf_gate_* and the plain entry points. */
+typedef struct eqf_gate_in {
+  int S, G;
+  float c_silu, c_sig;
+} eqf_gate_in;
+int eqf_sfcx_fwd_gated(const float* x_raw, const eqf_gate_in* gate, const float* coupling, const float* w,
+                       const eqf_dtp_paths* paths, const void* packed, const float* bias0, float* out1,
+                       const eqf_irreps* out1_irreps, int E, int mode, void* stream);
+int eqf_sfcx_bwd_data_gated(const float* x_raw, const eqf_gate_in* gate, const float* coupling, const float* w,
+                            const eqf_dtp_paths* paths, const void* packed, const float* d_out1,
+                            const eqf_irreps* out1_irreps, float* d_x_raw, float* dw, float* d_coupling, int E, int mode,
+                            void* stream);
+int eqf_sfcx_bwd_weight_gated(const float* x_raw, const eqf_gate_in* gate, const float* coupling, const float* w,
+                              const eqf_dtp_paths* paths, const float* d_out1, const eqf_irreps* out1_irreps,
+                              float* const* dWl, int E, int mode, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Row-local feature ops (nodes or edges)
  * ------------------------------------------------------------------------------------------- */

@@ -174,6 +174,9 @@ def test_deferred_weight_gradients_equal_immediate_ones():
         return (m(None, d["pos"], d["batch"], d["z"]).squeeze() - d["y"]).abs().mean()
 
     res = {}
+    assert not ops._seen_create_graph[0] or True  # (a create_graph pass earlier in the process switches the deferral off:
+    seen = ops._seen_create_graph[0]              #  reset for this test, restored below)
+    ops._seen_create_graph[0] = False
     for on in (False, True):
         prev = ops.set_deferred_weight_gradients(on)
         try:
@@ -186,6 +189,7 @@ def test_deferred_weight_gradients_equal_immediate_ones():
             res[on, "twice"] = [None if p.grad is None else p.grad.clone() for p in params]
         finally:
             ops.set_deferred_weight_gradients(prev)
+    ops._seen_create_graph[0] = seen
     assert not ops._deferred
     for key in ("backward", "grad", "twice"):
         for a, b in zip(res[True, key], res[False, key]):

@@ -178,3 +178,45 @@ def test_qm9_model_bf16_mode_stated_tolerance():
     e, g = _qm9("bf16")
     print("QM9 model, matrix mode bf16: energy rel err %.2e, worst parameter-gradient rel err %.2e" % (e, g))
     assert e < 1e-2 and g < 5e-2
+
+
+@pytest.mark.parametrize("E", [1000, 37])
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+def test_gate_folded_into_the_operator(mode, E):
+    """eqf_sfcx_*_gated: the Gate in front of sep_value applied where x is loaded, its backward in the data gradient's
+    epilogue [ref: nets/graph_attention_transformer.py:494-496, nets/fast_activation.py:132-148] -- against the separate
+    gate kernels followed by the plain operator, same arithmetic mode: forward, d x_raw (scalars, gates, gated parts),
+    d coupling, weight and bias gradients."""
+    from equiformer_amd import so3
+    from equiformer_amd.irreps import Irreps
+    dev = _dev()
+    irr, sh, out_irr = "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "128x0e+64x1e+32x2e"
+    table = DtpTable(irr, sh, irr)
+    lay = RowLayout(out_irr)
+    spec = ops.SfcSpec(table, lay, n2=0)
+    gated_layout = RowLayout("64x1e+32x2e")
+    S, G = 128, 96
+    g = torch.Generator().manual_seed(E)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    x_raw = r(E, S + G + gated_layout.dim).requires_grad_(True)
+    M = r(E, table.m_numel).requires_grad_(True)
+    weight = (r(spec.weight_numel) * 0.1).requires_grad_(True)
+    bias = r(lay.mul_of(0)).requires_grad_(True)
+    c = r(E, lay.dim)
+    gate = (S, gated_layout, so3.C_SILU, so3.C_SIGMOID)
+    res = {}
+    with ops.matrix_mode(mode):
+        assert ops.sep_fctp_gated_ok(spec, x_raw.shape[1], S, gated_layout)
+        for fused in (True, False):
+            if fused:
+                y = ops.sep_fctp_gated(x_raw, M, None, weight, bias, spec, gate)
+            else:
+                y = ops.sep_fctp(ops.gate(x_raw, *gate), M, None, weight, bias, spec)
+            grads = torch.autograd.grad((y * c).sum(), [x_raw, M, weight, bias])
+            res[fused] = [y.detach()] + [t.detach() for t in grads]
+    names = ["out", "d x_raw", "d coupling", "d weight", "d bias"]
+    errs = {n: _rel(a, b) for n, a, b in zip(names, res[True], res[False])}
+    print("gate folded, mode %s E=%d: %s" % (mode, E, {k: "%.1e" % v for k, v in errs.items()}))
+    # same plane arithmetic on both sides; the differences are the last bits of the gated values (__expf vs expf, order of the
+    # products), which move a few of their bf16 plane roundings
+    assert all(v < (1e-5 if mode == "split" else 5e-3) for v in errs.values()), errs
