@@ -260,6 +260,119 @@ __global__ __launch_bounds__(256) void gemmx_rows_kernel(const GXGroup g_byval) 
   }
 }
 
+// ------------------------------------------------------------------------------------- short-K rows kernel (kind 1, K <= 64)
+// The radial MLPs' last layers: E rows x 64 -> N (960 per module, 7 modules side by side).  With the generic kernel every 64 x 64
+// output tile is a workgroup of its own that loads and splits its A rows again (15 times per row tile) and lives for two K
+// steps: 41 685 short-lived workgroups, 415 us for 681 MB of output (tools/gemm_shapes.py).  Here a workgroup keeps the planes
+// of its 64 A rows in LDS and walks ALL column tiles of the problem: the next tile's weights are in flight (registers) while the
+// current tile multiplies and stores.
+constexpr int GW_K = 64;
+constexpr int GW_LDK = GW_K + 8;
+constexpr int GW_ROW = GX_T * GW_LDK;
+
+template <int NP>
+struct LoaderWide {  // 64 rows x K <= 64 floats, k contiguous: thread = (row t >> 2, quarter t & 3), 16-byte loads at k = 4 (q + 4 j)
+  float4 v[GW_K / 16];
+  __device__ __forceinline__ void issue(const GRows& R, int x0, int X, int K, bool two_level) {
+    const int row = x0 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    const bool rv = row < X;
+    const long off = two_level ? row_off2(rv ? row : x0, R.d, R.ld, R.inner) : (long)(rv ? row : x0) * R.ld;
+#pragma unroll
+    for (int j = 0; j < GW_K / 16; ++j) {
+      const int k = 4 * (q + 4 * j);
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rv && k < K) r = *reinterpret_cast<const float4*>(R.base + off + k);
+      v[j] = r;
+    }
+  }
+  __device__ __forceinline__ void commit(__bf16* __restrict__ T) const {
+    const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+#pragma unroll
+    for (int j = 0; j < GW_K / 16; ++j) {
+      const float f[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+      __bf16 p[NP][8];
+      split_n<NP>(f, 4, p);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        *reinterpret_cast<bf16x4_t*>(T + pl * GW_ROW + row * GW_LDK + 4 * (q + 4 * j)) = bf16x4_t{p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+    }
+  }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemmx_rows_wide_kernel(const GXGroup g_byval) {
+  KERNARG_IN_PLACE(GXGroup);
+  constexpr int NA = Planes<MODE>::A, NB = Planes<MODE>::W;
+  const GXP& P = g.p[blockIdx.z];
+  const int m0 = blockIdx.x * GX_T;
+  if (m0 >= P.M) return;
+  __shared__ __attribute__((aligned(16))) __bf16 As[NA * GW_ROW];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[NB * GW_ROW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  LoaderWide<NA> la;
+  LoaderWide<NB> lb;
+  la.issue(P.A, m0, P.M, P.K, true);
+  lb.issue(P.B, 0, P.N, P.K, false);
+  la.commit(As);
+  // this lane's output rows (fixed for the whole walk): tile row (q & 3) + 8 (q >> 2) + 4 hi
+  const bool flat_c = P.C.d == 1;
+  const SmallDiv cdiv(P.C.d);
+  float* const cbase = const_cast<float*>(P.C.base);
+  const int rb = m0 + wm0 + 4 * hi;
+  long off0;
+  int rem0 = 0;
+  if (flat_c) {
+    off0 = (long)rb * P.C.ld;
+  } else {
+    const int qb = rb / P.C.d;
+    rem0 = rb - qb * P.C.d;
+    off0 = (long)qb * P.C.ld;
+  }
+  const int nkt = (P.K + 15) / 16;
+  for (int n0 = 0; n0 < P.N; n0 += GX_T) {
+    __syncthreads();  // the previous tile's fragments are read (and, first time round, As is complete after the next barrier)
+    lb.commit(Bs);
+    __syncthreads();
+    if (n0 + GX_T < P.N) lb.issue(P.B, n0 + GX_T, P.N, P.K, false);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < GW_K / 16; ++kt) {
+      if (kt < nkt) {  // uniform
+        bf16x8 a[NA], b[NB];
+#pragma unroll
+        for (int q = 0; q < NA; ++q) a[q] = *reinterpret_cast<const bf16x8*>(As + q * GW_ROW + (wm0 + r) * GW_LDK + 16 * kt + 8 * hi);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bs + q * GW_ROW + (wn0 + r) * GW_LDK + 16 * kt + 8 * hi);
+        mma_terms<NA, NB>(a, b, acc);
+      }
+    }
+    const int col = n0 + wn0 + r;
+    if (col < P.N) {
+      const float bv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int dr = (q & 3) + 8 * (q >> 2);
+        if (rb + dr < P.M) {
+          long off;
+          if (flat_c) {
+            off = off0 + (long)dr * P.C.ld;
+          } else {
+            const int t = rem0 + dr, dq = cdiv.div(t);
+            off = off0 + (long)dq * P.C.ld + (long)(t - dq * P.C.d) * P.C.inner;
+          }
+          float* p = cbase + off + col;
+          float v = acc[q] + bv;
+          if (P.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------- weight gradients (kinds 2, 3)
 template <int MODE>
 __global__ __launch_bounds__(256) void gemmx_tn_kernel(const GXGroup g_byval) {
@@ -506,12 +619,17 @@ inline bool rows_vec_ok(const float* base, const eqf_rows& r) { return aligned16
 // development switch (eqf_gemmx_dev_set key 0): 0 = the one-wave-per-tile kernels for node-row problems, anything else = the
 // LDS-tiled kernels for every problem (the default: the two measure the same, tools/gemm_shapes.py, profiles/r04/r04_j_*)
 static int g_gemmx_no_direct = 1;
+static int g_gemmx_no_wide = 0;  // key 1: 1 = the generic tiled kernel for the short-K, many-row problems too (A/B)
 
 extern "C" {
 
 int eqf_gemmx_dev_set(int key, int value) {
   if (key == 0) {
     g_gemmx_no_direct = value;
+    return 0;
+  }
+  if (key == 1) {
+    g_gemmx_no_wide = value;
     return 0;
   }
   return EQF_E_BADARG;
@@ -527,7 +645,7 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
   static thread_local GXGroup G;
   for (int kind = 0; kind < 2; ++kind) {
     memset(&G, 0, sizeof G);
-    int maxm = 0, maxn = 0, big = 0, direct_ok = 1;
+    int maxm = 0, maxn = 0, big = 0, direct_ok = 1, wide_ok = 1;
     double flops = 0, bytes = 0;
     for (int i = 0; i < n; ++i) {
       if (d[i].kind != kind || d[i].M <= 0 || d[i].N <= 0) continue;
@@ -540,6 +658,7 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
       P.vecA = rows_vec_ok(d[i].A, d[i].ra);
       P.vecB = aligned16(d[i].B) && d[i].ldb % 4 == 0;
       if (P.K % 16 != 0 || !P.vecA || (kind == 1 && !P.vecB)) direct_ok = 0;
+      if (!(kind == 1 && P.K <= GW_K && P.K % 4 == 0 && P.vecA && P.vecB && P.M >= 8192 && P.N >= 2 * GX_T)) wide_ok = 0;
       if (eqf_cdiv(P.M, GX_T) > maxm) maxm = eqf_cdiv(P.M, GX_T);
       if (eqf_cdiv(P.N, GX_T) > maxn) maxn = eqf_cdiv(P.N, GX_T);
       if (P.M >= 32768 / 2 + 1) big = 1;  // more than 16 k rows: edge rows
@@ -550,12 +669,15 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
     // few rows (node-level linears): one wave per 32 x 32 tile, whole K chunks in flight; many rows (edge-level: the radial
     // MLPs): the LDS-tiled kernel.  Timed under different names.
     const bool direct = !big && direct_ok && !g_gemmx_no_direct;
-    dim3 grid(direct ? 2 * maxm : maxm, direct ? 2 * maxn : maxn, G.n);
+    const bool wide = kind == 1 && wide_ok && !g_gemmx_no_wide;
+    dim3 grid(direct ? 2 * maxm : maxm, wide ? 1 : (direct ? 2 * maxn : maxn), G.n);
     const int pid = eqf_prof_begin(kind == 0 ? (big ? "gemmx_group_kn_edge" : "gemmx_group_kn_node")
                                              : (big ? "gemmx_group_nk_edge" : "gemmx_group_nk_node"), st, flops, bytes);
 #define GX_ROWS(M_)                                                                                              \
   do {                                                                                                           \
-    if (direct) {                                                                                                \
+    if (wide) {                                                                                                  \
+      hipLaunchKernelGGL((gemmx_rows_wide_kernel<M_>), grid, dim3(256), 0, st, G);                              \
+    } else if (direct) {                                                                                         \
       if (kind == 0) hipLaunchKernelGGL((gemmx_rows_direct_kernel<M_, 0>), grid, dim3(64), 0, st, G);           \
       else hipLaunchKernelGGL((gemmx_rows_direct_kernel<M_, 1>), grid, dim3(64), 0, st, G);                     \
     } else if (kind == 0) hipLaunchKernelGGL((gemmx_rows_kernel<M_, 0>), grid, dim3(256), 0, st, G);            \

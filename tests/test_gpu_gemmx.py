@@ -84,7 +84,8 @@ def test_irreps_linear_all_kinds(case, mode):
 
 
 @pytest.mark.parametrize("mode", ["split", "bf16"])
-@pytest.mark.parametrize("shape", [(25354, 128, 64), (1000, 64, 960), (37, 32, 64), (513, 64, 64)])
+@pytest.mark.parametrize("shape", [(25354, 128, 64), (1000, 64, 960), (37, 32, 64), (513, 64, 64),
+                                   (8200, 64, 960), (9001, 32, 200)])  # the last two: the short-K walk-all-columns kernel
 def test_dense_linear_all_kinds(shape, mode):
     """nn.Linear orientation (weight [N, K]) of the radial MLPs: forward, data gradient, weight + bias gradient"""
     M, K, N = shape
