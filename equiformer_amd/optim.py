@@ -62,19 +62,22 @@ class FlatAdamW(torch.optim.Optimizer):
         self._reducer = reducer
         dev = ps[0].device
         self.sizes = [p.numel() for p in ps]
-        n = self.n = sum(self.sizes)
-        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        from .parallel import flat_offsets
+        self.offsets, n = flat_offsets(self.sizes)  # every slice starts 256-byte aligned (same layout as the reducer's)
+        self.n = n
+        if reducer is not None and (list(reducer.offsets) != self.offsets or reducer.flat.numel() != n):
+            raise ValueError("reducer and optimizer flat layouts differ")
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_wd = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_wd = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = reducer.flat if reducer is not None else torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_ema = None
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         wd_of = {id(p): g["weight_decay"] for g in self.param_groups for p in g["params"]}
-        off = 0
         self._gviews = []
         with torch.no_grad():
-            for p, k in zip(ps, self.sizes):
+            for p, k, off in zip(ps, self.sizes, self.offsets):
                 self.flat_p[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat_p[off:off + k].view_as(p)  # the parameter now aliases the flat buffer
                 self.flat_wd[off:off + k].fill_(float(wd_of[id(p)]))
@@ -83,7 +86,6 @@ class FlatAdamW(torch.optim.Optimizer):
                 st["step"] = 0
                 st["exp_avg"] = self.flat_m[off:off + k].view_as(p)
                 st["exp_avg_sq"] = self.flat_v[off:off + k].view_as(p)
-                off += k
         if ema_decay is not None:
             self.flat_ema = self.flat_p.clone()
         self._step = 0
@@ -108,13 +110,10 @@ class FlatAdamW(torch.optim.Optimizer):
             raise RuntimeError("FlatAdamW was built without ema_decay")
         m = copy.deepcopy(model)
         by_id = {id(p): i for i, p in enumerate(self._params)}
-        offs = [0]
-        for k in self.sizes:
-            offs.append(offs[-1] + k)
         for (_, src), (_, dst) in zip(model.named_parameters(), m.named_parameters()):
             i = by_id.get(id(src))
             if i is not None:
-                dst.data = self.flat_ema[offs[i]:offs[i + 1]].view_as(src)
+                dst.data = self.flat_ema[self.offsets[i]:self.offsets[i] + self.sizes[i]].view_as(src)
             dst.requires_grad_(False)
         return m
 
@@ -130,10 +129,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 raise ValueError("FlatAdamW: lr / betas / eps must agree across parameter groups")
         # gradients -> flat buffer (already there when the reducer re-pointed .grad at its slices)
         src, dst, zero, slow, nograd = [], [], [], [], set()
-        off = 0
-        offs = []
-        for i, (p, v, k) in enumerate(zip(self._params, self._gviews, self.sizes)):
-            offs.append(off)
+        offs = self.offsets
+        for i, (p, v, k, off) in enumerate(zip(self._params, self._gviews, self.sizes, self.offsets)):
             if p.grad is None:
                 zero.append(v)
                 nograd.add(i)
@@ -144,7 +141,6 @@ class FlatAdamW(torch.optim.Optimizer):
                     dst.append(v)
                 if self._lag[i] > 0:
                     slow.append((i, off, k, True))
-            off += k
         # torch.optim.AdamW skips a parameter without a gradient entirely (no decay, no moment decay, its own step
         # count is not advanced).  The kernel does the same for elements whose weight-decay entry is negative; the
         # marks are rewritten only when the SET of gradient-less parameters changes (in practice never after the
@@ -218,10 +214,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
                 step = max(step, int(st["step"]))
             wd_of = {id(p): g["weight_decay"] for g in self.param_groups for p in g["params"]}
-            off = 0
-            for p, k in zip(self._params, self.sizes):
+            for p, k, off in zip(self._params, self.sizes, self.offsets):
                 self.flat_wd[off:off + k].fill_(float(wd_of[id(p)]))
-                off += k
             self._wd_value = [float(wd_of[id(p)]) for p in self._params]
             self._skipped = set()  # the skip marks went with the rewrite; step() puts them back
         self._step = step

@@ -24,6 +24,21 @@ import torch
 import torch.distributed as dist
 
 
+FLAT_ALIGN = 64  # floats (256 bytes): every parameter's slice of a flat buffer starts on such a boundary
+
+
+def flat_offsets(sizes, align=FLAT_ALIGN):
+    """(offsets, total) of tensors of `sizes` elements laid out one after the other, each start rounded up to `align` elements:
+    parameters that alias a flat buffer stay 16-byte aligned (the kernels' 16-byte loads of weights, the packed-plane kernels)
+    whatever odd-sized tensors precede them.  The padding elements are zero in every buffer and stay zero (AdamW of 0 with
+    gradient 0).  Shared by FlatGradAllReduce and FlatAdamW so that the two layouts coincide."""
+    offs, off = [], 0
+    for k in sizes:
+        offs.append(off)
+        off += (int(k) + align - 1) // align * align
+    return offs, off
+
+
 class FlatGradAllReduce:
     """Owns a flat buffer aliased by every parameter's .grad after `reduce()`; averages it across the ranks.
 
@@ -43,16 +58,10 @@ class FlatGradAllReduce:
         late = {id(p) for p in getattr(module, "late_gradient_parameters", lambda: [])()}
         self.params = [p for p in params if id(p) in late] + [p for p in params if id(p) not in late]
         self.group = process_group
-        n = sum(p.numel() for p in self.params)
+        self.offsets, n = flat_offsets([p.numel() for p in self.params])
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        self.views, self.offsets = [], []
-        for p in self.params:
-            v = self.flat[off:off + p.numel()].view_as(p)
-            self.views.append(v)
-            self.offsets.append(off)
-            off += p.numel()
+        self.views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
         # cut: parameters [k, end) form the tail bucket.  Every tail parameter reports its gradient through a
         # post-accumulate hook; the collective is launched by whichever arrives LAST, in whatever order autograd runs the
         # nodes.  (One backward() per reduce(): with several micro-batch backwards the first one would launch it.)

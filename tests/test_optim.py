@@ -90,22 +90,30 @@ def test_flat_adamw_state_dict_round_trip_keeps_flat_aliasing():
     before = [p.detach().clone() for p in ps]
     assert all(p.data_ptr() >= a.flat_p.data_ptr() and p.data_ptr() < a.flat_p.data_ptr() + 4 * a.n for p in ps)
     assert all(torch.equal(p.detach(), b) for p, b in zip(ps, before))
-    assert torch.equal(a.flat_wd, torch.tensor([0.0] * 12 + [0.01] * 9))
+    # every parameter's slice starts 256-byte aligned (64 floats): offsets 0, 64, 128; the padding is zero
+    assert a.offsets == [0, 64, 128] and a.n == 192
+    want_wd = torch.zeros(192)
+    want_wd[64:69], want_wd[128:132] = 0.01, 0.01
+    assert torch.equal(a.flat_wd, want_wd)
+    assert all(p.data_ptr() % 16 == 0 for p in ps)
     a.flat_m.copy_(torch.arange(a.n, dtype=torch.float32))
     a.flat_v.copy_(torch.arange(a.n, dtype=torch.float32) * 2)
     a._step = 7
     for p in ps:
         a.state[p]["step"] = 7
     sd = a.state_dict()
-    assert sd["state"][1]["exp_avg"].tolist() == list(range(12, 17)) and sd["state"][2]["step"] == 7
+    assert sd["state"][1]["exp_avg"].tolist() == list(range(64, 69)) and sd["state"][2]["step"] == 7
     assert [len(g["params"]) for g in sd["param_groups"]] == [1, 2]
     ps2, b = make(1)
     sd["param_groups"][0]["lr"] = sd["param_groups"][1]["lr"] = 5e-4
     b.load_state_dict(sd)
-    assert torch.equal(b.flat_m, a.flat_m) and torch.equal(b.flat_v, a.flat_v) and b._step == 7
+    # the parameters' slices are restored (the test wrote into the padding of `a` as well; `b`'s padding stays zero)
+    for o, k in zip(a.offsets, a.sizes):
+        assert torch.equal(b.flat_m[o:o + k], a.flat_m[o:o + k]) and torch.equal(b.flat_v[o:o + k], a.flat_v[o:o + k])
+    assert b._step == 7
     assert b.param_groups[0]["lr"] == 5e-4 and b.state[ps2[2]]["step"] == 7
     m = b.state[ps2[1]]["exp_avg"]
-    assert m.data_ptr() == b.flat_m.data_ptr() + 4 * 12  # still a view of the flat buffer
+    assert m.data_ptr() == b.flat_m.data_ptr() + 4 * b.offsets[1]  # still a view of the flat buffer
     em = b.ema_module(torch.nn.ParameterList(ps2))
     assert all(not q.requires_grad for q in em.parameters())
     assert next(iter(em.parameters())).data_ptr() == b.flat_ema.data_ptr()
@@ -218,8 +226,6 @@ def test_flat_adamw_leaves_gradless_parameters_untouched():
         ema = [0.9 * e + 0.1 * p.detach() for e, p in zip(ema, tb)]
     for pa, pb in zip(ta, tb):
         assert (pa.detach() - pb.detach()).abs().max() <= 2e-6 * max(1.0, float(pa.detach().abs().max()))
-    off = 0
-    for e, p in zip(ema, tb):
+    for e, p, off in zip(ema, tb, ob.offsets):  # (every slice of the flat buffers starts 256-byte aligned)
         got = ob.flat_ema[off:off + p.numel()]
         assert (got - e).abs().max() <= 2e-6
-        off += p.numel()

@@ -88,8 +88,21 @@ def test_two_rank_gloo_flat_allreduce_matches_full_batch(tmp_path):
     _loss(model, d, range(4)).backward()
     full = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                       for p in model.parameters() if p.requires_grad])
-    err = ((full - r0["flat"]).abs().max() / full.abs().max()).item()
+    got = _unpad(r0["flat"], [p.numel() for p in model.parameters() if p.requires_grad])
+    err = ((full - got).abs().max() / full.abs().max()).item()
     assert err < 1e-5, err
+
+
+def _unpad(flat, sizes):
+    """the parameters' slices of a flat buffer (each starts 256-byte aligned: equiformer_amd.parallel.flat_offsets), concatenated"""
+    from equiformer_amd.parallel import flat_offsets
+    offs, n = flat_offsets(sizes)
+    assert flat.numel() == n
+    pad = torch.ones(n, dtype=torch.bool)
+    for o, k in zip(offs, sizes):
+        pad[o:o + k] = False
+    assert (flat[pad] == 0).all(), "padding elements of the flat gradient must stay zero"
+    return torch.cat([flat[o:o + k] for o, k in zip(offs, sizes)])
 
 
 class _Toy(torch.nn.Module):
