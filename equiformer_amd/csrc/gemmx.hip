@@ -91,31 +91,35 @@ struct LoaderKC {
       roff[pass] = row_off2(rv[pass] ? x : x0, R.d, R.ld, R.inner);
     }
   }
-  __device__ __forceinline__ void issue(const GRows& R, int k0, int K, bool vec) {
-    const int kq = threadIdx.x & 7;
+  // Every load is UNCONDITIONAL (address clamped into the row; commit() zeroes what lies outside): a load behind a per-lane
+  // branch is waited for at the end of that branch, which serialises the round trips of a step (measured on the weight-gradient
+  // kernel: 16 branched loads per step = 2.5 us per step, profiles/r04/r04_y_tn_minsteps.txt).  The zeroing is in commit() so
+  // that nothing between issue() and commit() -- the MFMAs of the previous step -- depends on the loads.
+  int krem;  // of the step in flight: K - (k0 + 4 kq)
+  template <bool VEC>  // a template parameter, not a kernel argument: the loads of a UNIFORM branch are waited for at its end too
+  __device__ __forceinline__ void issue(const GRows& R, int k0, int K) {
+    const int k = k0 + 4 * (threadIdx.x & 7);
+    krem = K - k;
+    if constexpr (VEC) {  // rows 16-byte aligned and K % 4 == 0: a quad is whole or absent
+      const int kc = krem > 0 ? k : 0;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int krem = K - (k0 + 4 * kq);
-      if (rv[pass] && krem > 0) {
-        const float* p = R.base + roff[pass] + k0 + 4 * kq;
-        if (vec && krem >= 4) {
-          r = *reinterpret_cast<const float4*>(p);
-        } else {
-          r.x = p[0];
-          if (krem > 1) r.y = p[1];
-          if (krem > 2) r.z = p[2];
-          if (krem > 3) r.w = p[3];
-        }
+      for (int pass = 0; pass < 2; ++pass) v[pass] = *reinterpret_cast<const float4*>(R.base + roff[pass] + kc);
+    } else {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const float* const p = R.base + roff[pass];
+        v[pass] = make_float4(p[min(k, K - 1)], p[min(k + 1, K - 1)], p[min(k + 2, K - 1)], p[min(k + 3, K - 1)]);
       }
-      v[pass] = r;
     }
   }
   __device__ __forceinline__ void commit(__bf16* __restrict__ T) const {  // T: [NP][64][GX_LDK]
     const int kq = threadIdx.x & 7, xr0 = threadIdx.x >> 3;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      const float f[4] = {v[pass].x, v[pass].y, v[pass].z, v[pass].w};
+      float f[4] = {v[pass].x, v[pass].y, v[pass].z, v[pass].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(rv[pass] && e < krem)) f[e] = 0.f;
       __bf16 p[NP][8];
       split_n<NP>(f, 4, p);
 #pragma unroll
@@ -127,24 +131,46 @@ struct LoaderKC {
 };
 
 // ---- ks: 32 reduction rows (two-level index k0 + k) x 64 tile columns contiguous in memory; thread = (column x, k group kg)
+// The two-level row index (k / d, k % d) is WALKED, not divided: one exact division in init(), then +1 per row and +32 per step
+// with a wrap.  (A division per load -- 16 per step and thread -- made the K loop of the weight-gradient kernel ~860 VALU
+// instructions per step with one wave per SIMD: 1.7 us per step whatever else the step did, profiles/r04/r04_aa_*.)
 template <int NP>
 struct LoaderKS {
   float v[8];
-  float cs;  // running column sum of the fp32 values this thread staged (bias gradients)
-  __device__ __forceinline__ void init() { cs = 0.f; }
-  __device__ __forceinline__ void issue(const GRows& R, int k0, int K, int x0, int X) {
-    const int x = x0 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+  float cs;   // running column sum of the fp32 values this thread staged (bias gradients)
+  int kleft;  // of the step in flight: valid reduction rows of this thread's group of 8 (may be <= 0); < 0 for a column past X
+  int kb, q, rem;  // this thread's first reduction row of the NEXT step, and its two-level index
+  __device__ __forceinline__ void init(const GRows& R, int k_first) {
+    cs = 0.f;
+    kb = k_first + 8 * (threadIdx.x >> 6);
+    q = kb / R.d;
+    rem = kb - q * R.d;
+  }
+  // loads the step at kb (unconditional loads, as above) and moves on by GX_BK rows
+  __device__ __forceinline__ void issue(const GRows& R, int K, int x0, int X) {
+    const int x = x0 + (threadIdx.x & 63);
     const bool xv = x < X;
+    const int nv = K - kb;  // rows of the group inside the matrix
+    kleft = xv ? nv : -1;
+    // a group that starts past the end reads row 0 (never used)
+    const float* const p = R.base + (xv ? x : x0) + (nv > 0 ? (long)q * R.ld + (long)rem * R.inner : 0L);
+    const int wrap = R.ld - R.d * R.inner;
+    int rel = 0, r = rem;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int k = k0 + 8 * kg + j;
-      float r = 0.f;
-      if (xv && k < K) r = R.base[row_off2(k, R.d, R.ld, R.inner) + x];
-      v[j] = r;
+      v[j] = p[j < nv ? rel : 0];
+      rel += R.inner;
+      if (++r == R.d) r = 0, rel += wrap;
     }
+    const int q32 = GX_BK / R.d, r32 = GX_BK - q32 * R.d;  // uniform
+    kb += GX_BK, q += q32, rem += r32;
+    if (rem >= R.d) rem -= R.d, ++q;
   }
   __device__ __forceinline__ void commit(__bf16* __restrict__ T, bool want_cs) {
     const int x = threadIdx.x & 63, kg = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j >= kleft) v[j] = 0.f;
     if (want_cs) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) cs += v[j];
@@ -152,9 +178,9 @@ struct LoaderKS {
     __bf16 p[NP][8];
     split_n<NP>(v, 8, p);
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
-      *reinterpret_cast<bf16x8*>(T + q * GX_ROW + x * GX_LDK + 8 * kg) =
-          bf16x8{p[q][0], p[q][1], p[q][2], p[q][3], p[q][4], p[q][5], p[q][6], p[q][7]};
+    for (int q_ = 0; q_ < NP; ++q_)
+      *reinterpret_cast<bf16x8*>(T + q_ * GX_ROW + x * GX_LDK + 8 * kg) =
+          bf16x8{p[q_][0], p[q_][1], p[q_][2], p[q_][3], p[q_][4], p[q_][5], p[q_][6], p[q_][7]};
   }
 };
 
@@ -174,7 +200,7 @@ __device__ __forceinline__ void gx_mma(const __bf16* __restrict__ As, const __bf
 }
 
 // ------------------------------------------------------------------------------------------------ rows kernels (kinds 0, 1)
-template <int MODE, int BKIND>
+template <int MODE, int BKIND, bool VEC>
 __global__ __launch_bounds__(256) void gemmx_rows_kernel(const GXGroup g_byval) {
   KERNARG_IN_PLACE(GXGroup);
   constexpr int NA = Planes<MODE>::A, NB = Planes<MODE>::W;
@@ -193,13 +219,13 @@ __global__ __launch_bounds__(256) void gemmx_rows_kernel(const GXGroup g_byval) 
   LoaderKC<NB> lbk;
   LoaderKS<NB> lbs;
   la.init(P.A, m0, P.M);
-  la.issue(P.A, 0, P.K, P.vecA);
+  la.template issue<VEC>(P.A, 0, P.K);
   if constexpr (BKIND == 1) {
     lbk.init(P.B, n0, P.N);
-    lbk.issue(P.B, 0, P.K, P.vecB);
+    lbk.template issue<VEC>(P.B, 0, P.K);
   } else {
-    lbs.init();
-    lbs.issue(P.B, 0, P.K, n0, P.N);
+    lbs.init(P.B, 0);
+    lbs.issue(P.B, P.K, n0, P.N);
   }
   la.commit(As[0]);
   if constexpr (BKIND == 1) lbk.commit(Bs[0]);
@@ -209,9 +235,9 @@ __global__ __launch_bounds__(256) void gemmx_rows_kernel(const GXGroup g_byval) 
   for (int k0 = 0; k0 < P.K; k0 += GX_BK) {
     const bool more = k0 + GX_BK < P.K;
     if (more) {
-      la.issue(P.A, k0 + GX_BK, P.K, P.vecA);
-      if constexpr (BKIND == 1) lbk.issue(P.B, k0 + GX_BK, P.K, P.vecB);
-      else lbs.issue(P.B, k0 + GX_BK, P.K, n0, P.N);
+      la.template issue<VEC>(P.A, k0 + GX_BK, P.K);
+      if constexpr (BKIND == 1) lbk.template issue<VEC>(P.B, k0 + GX_BK, P.K);
+      else lbs.issue(P.B, P.K, n0, P.N);
     }
     gx_mma<NA, NB>(As[cur], Bs[cur], wm0, wn0, acc);
     if (more) {
@@ -273,23 +299,24 @@ constexpr int GW_ROW = GX_T * GW_LDK;
 template <int NP>
 struct LoaderWide {  // 64 rows x K <= 64 floats, k contiguous: thread = (row t >> 2, quarter t & 3), 16-byte loads at k = 4 (q + 4 j)
   float4 v[GW_K / 16];
+  int kv;  // valid k of this thread's row (0 for a row past X); unconditional loads, zeroing in commit (see LoaderKC)
   __device__ __forceinline__ void issue(const GRows& R, int x0, int X, int K, bool two_level) {
     const int row = x0 + (threadIdx.x >> 2), q = threadIdx.x & 3;
     const bool rv = row < X;
+    kv = rv ? K : 0;
     const long off = two_level ? row_off2(rv ? row : x0, R.d, R.ld, R.inner) : (long)(rv ? row : x0) * R.ld;
 #pragma unroll
-    for (int j = 0; j < GW_K / 16; ++j) {
+    for (int j = 0; j < GW_K / 16; ++j) {  // K % 4 == 0 here
       const int k = 4 * (q + 4 * j);
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rv && k < K) r = *reinterpret_cast<const float4*>(R.base + off + k);
-      v[j] = r;
+      v[j] = *reinterpret_cast<const float4*>(R.base + off + (k < K ? k : 0));
     }
   }
   __device__ __forceinline__ void commit(__bf16* __restrict__ T) const {
     const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
 #pragma unroll
     for (int j = 0; j < GW_K / 16; ++j) {
-      const float f[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+      const bool ok = 4 * (q + 4 * j) < kv;
+      const float f[4] = {ok ? v[j].x : 0.f, ok ? v[j].y : 0.f, ok ? v[j].z : 0.f, ok ? v[j].w : 0.f};
       __bf16 p[NP][8];
       split_n<NP>(f, 4, p);
 #pragma unroll
@@ -398,10 +425,10 @@ __global__ __launch_bounds__(256) void gemmx_tn_kernel(const GXGroup g_byval) {
   const bool csA = P.kind == 3 && P.cs != nullptr && blockIdx.y == 0;
   const bool csB = P.kind == 2 && P.cs != nullptr && blockIdx.x == 0;
   LoaderKS<NA> la, lb;
-  la.init();
-  lb.init();
-  la.issue(P.A, s_beg * GX_BK, P.K, m0, P.M);
-  lb.issue(P.B, s_beg * GX_BK, P.K, n0, P.N);
+  la.init(P.A, s_beg * GX_BK);
+  lb.init(P.B, s_beg * GX_BK);
+  la.issue(P.A, P.K, m0, P.M);
+  lb.issue(P.B, P.K, n0, P.N);
   la.commit(As[0], csA);
   lb.commit(Bs[0], csB);
   __syncthreads();
@@ -409,8 +436,8 @@ __global__ __launch_bounds__(256) void gemmx_tn_kernel(const GXGroup g_byval) {
   for (int s = s_beg; s < s_end; ++s) {
     const bool more = s + 1 < s_end;
     if (more) {
-      la.issue(P.A, (s + 1) * GX_BK, P.K, m0, P.M);
-      lb.issue(P.B, (s + 1) * GX_BK, P.K, n0, P.N);
+      la.issue(P.A, P.K, m0, P.M);
+      lb.issue(P.B, P.K, n0, P.N);
     }
     gx_mma<NA, NA>(As[cur], Bs[cur], wm0, wn0, acc);
     if (more) {
@@ -619,7 +646,9 @@ inline bool rows_vec_ok(const float* base, const eqf_rows& r) { return aligned16
 // development switch (eqf_gemmx_dev_set key 0): 0 = the one-wave-per-tile kernels for node-row problems, anything else = the
 // LDS-tiled kernels for every problem (the default: the two measure the same, tools/gemm_shapes.py, profiles/r04/r04_j_*)
 static int g_gemmx_no_direct = 1;
-static int g_gemmx_no_wide = 0;  // key 1: 1 = the generic tiled kernel for the short-K, many-row problems too (A/B)
+static int g_gemmx_no_wide = 0;
+static int g_gemmx_tn_minsteps = 8;   // key 2: K steps per workgroup of a weight gradient at least (sweep: profiles/r04/r04_y_*)
+// key 1: 1 = the generic tiled kernel for the short-K, many-row problems too (A/B)
 
 extern "C" {
 
@@ -630,6 +659,10 @@ int eqf_gemmx_dev_set(int key, int value) {
   }
   if (key == 1) {
     g_gemmx_no_wide = value;
+    return 0;
+  }
+  if (key == 2 && value >= 1) {
+    g_gemmx_tn_minsteps = value;
     return 0;
   }
   return EQF_E_BADARG;
@@ -645,7 +678,7 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
   static thread_local GXGroup G;
   for (int kind = 0; kind < 2; ++kind) {
     memset(&G, 0, sizeof G);
-    int maxm = 0, maxn = 0, big = 0, direct_ok = 1, wide_ok = 1;
+    int maxm = 0, maxn = 0, big = 0, direct_ok = 1, wide_ok = 1, vec_ok = 1;
     double flops = 0, bytes = 0;
     for (int i = 0; i < n; ++i) {
       if (d[i].kind != kind || d[i].M <= 0 || d[i].N <= 0) continue;
@@ -658,6 +691,7 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
       P.vecA = rows_vec_ok(d[i].A, d[i].ra);
       P.vecB = aligned16(d[i].B) && d[i].ldb % 4 == 0;
       if (P.K % 16 != 0 || !P.vecA || (kind == 1 && !P.vecB)) direct_ok = 0;
+      if (P.K % 4 != 0 || !P.vecA || (kind == 1 && !P.vecB)) vec_ok = 0;  // one unaligned problem: scalar loads for the group
       if (!(kind == 1 && P.K <= GW_K && P.K % 4 == 0 && P.vecA && P.vecB && P.M >= 8192 && P.N >= 2 * GX_T)) wide_ok = 0;
       if (eqf_cdiv(P.M, GX_T) > maxm) maxm = eqf_cdiv(P.M, GX_T);
       if (eqf_cdiv(P.N, GX_T) > maxn) maxn = eqf_cdiv(P.N, GX_T);
@@ -680,8 +714,13 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
     } else if (direct) {                                                                                         \
       if (kind == 0) hipLaunchKernelGGL((gemmx_rows_direct_kernel<M_, 0>), grid, dim3(64), 0, st, G);           \
       else hipLaunchKernelGGL((gemmx_rows_direct_kernel<M_, 1>), grid, dim3(64), 0, st, G);                     \
-    } else if (kind == 0) hipLaunchKernelGGL((gemmx_rows_kernel<M_, 0>), grid, dim3(256), 0, st, G);            \
-    else hipLaunchKernelGGL((gemmx_rows_kernel<M_, 1>), grid, dim3(256), 0, st, G);                             \
+    } else if (kind == 0) {                                                                                      \
+      if (vec_ok) hipLaunchKernelGGL((gemmx_rows_kernel<M_, 0, true>), grid, dim3(256), 0, st, G);              \
+      else hipLaunchKernelGGL((gemmx_rows_kernel<M_, 0, false>), grid, dim3(256), 0, st, G);                    \
+    } else {                                                                                                     \
+      if (vec_ok) hipLaunchKernelGGL((gemmx_rows_kernel<M_, 1, true>), grid, dim3(256), 0, st, G);              \
+      else hipLaunchKernelGGL((gemmx_rows_kernel<M_, 1, false>), grid, dim3(256), 0, st, G);                    \
+    }                                                                                                            \
   } while (0)
     if (mode == 0) GX_ROWS(0);
     else if (mode == 1) GX_ROWS(1);
@@ -706,7 +745,10 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
       const int tiles = eqf_cdiv(P.M, GX_T) * eqf_cdiv(P.N, GX_T);
       const int total_steps = eqf_cdiv(P.K, GX_BK);
       int ksplit = 1024 / (tiles > 0 ? tiles : 1);
-      const int max_split = eqf_cdiv(total_steps, 8);  // at least 8 steps (256 reduction rows) per workgroup
+      // at least g_gemmx_tn_minsteps K steps per workgroup.  Longer walks are NOT cheaper: the time of these launches follows
+      // the steps per workgroup (8 / 16 / 24 / 48 / 96 steps: 25 / 40 / 57 / 101 / 192 us for the 480 x 480 node-row gradient),
+      // the 64 x 64 atomics per split do not show
+      const int max_split = eqf_cdiv(total_steps, g_gemmx_tn_minsteps);
       if (ksplit > max_split) ksplit = max_split;
       if (ksplit < 1) ksplit = 1;
       P.steps_per_split = eqf_cdiv(total_steps, ksplit);

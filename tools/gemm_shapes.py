@@ -35,6 +35,9 @@ def timeit(fn, k=30):
 _lib.load()
 if DIRECT:
     _lib.load().eqf_gemmx_dev_set(0, 0)
+for a in sys.argv:
+    if a.startswith("--tn-minsteps="):
+        _lib.load().eqf_gemmx_dev_set(2, int(a.split("=")[1]))
 rows = []
 CASES = [("node 480 -> 480", "128x0e+64x1e+32x2e", "128x0e+64x1e+32x2e"),
          ("node ffn 480 -> 3x", "128x0e+64x1e+32x2e", "384x0e+192x1e+96x2e"),
