@@ -26,6 +26,7 @@
 //       reduction index is the feature row): lane = column, eight 4-byte loads down the reduction index (each a coalesced
 //       256-byte run), one 16-byte LDS write per plane; the bias gradient's column sums are taken from the fp32 registers.
 // Compiled with -fno-slp-vectorize (no packed-FP32 VALU beside bf16 MFMAs, as sfcx.hip).
+#include <climits>
 #include "sfcx_common.h"
 
 namespace {
@@ -54,12 +55,23 @@ struct GXP {          // one problem
   int vecA, vecB;
   int steps_per_split;
 };
-static_assert(sizeof(GXP) * GX_MAXP + 4 * (GX_MAXP + 2) <= 4000, "kernarg segment");
+static_assert(sizeof(GXP) * GX_MAXP + 4 * (2 * GX_MAXP + 3) <= 4000, "kernarg segment");
 struct GXGroup {
   int n;
-  int zoff[GX_MAXP + 1];  // tn: blockIdx.z -> (problem, split)
+  int zoff[GX_MAXP + 1];  // one-wave-per-tile kernels (development switch): blockIdx.z -> (problem, K chunk)
+  // LDS-tiled kernels: ONE-dimensional grid, workgroup b belongs to problem i with woff[i] <= b < woff[i + 1] (entries past n
+  // are INT_MAX).  A (max tiles m, max tiles n, problems) grid launched mostly EMPTY workgroups when the problems of a group
+  // differ in shape -- 23 k workgroups for the ~1 200 of a 24-problem weight-gradient group, 146 us per launch.
+  int woff[GX_MAXP + 1];
   GXP p[GX_MAXP];
 };
+
+__device__ __forceinline__ int flat_problem(const GXGroup& g, int b) {  // branch-free: the table comes in a few wide scalar loads
+  int pi = 0;
+#pragma unroll
+  for (int j = 1; j < GX_MAXP; ++j) pi += (int)((unsigned)(g.woff[j] - 1 - b) >> 31);  // sign bit of woff[j] - 1 - b: b >= woff[j]
+  return pi;
+}
 
 template <int NP>
 __device__ __forceinline__ void split_n(const float* v, int n, __bf16 (*p)[8]) {
@@ -204,9 +216,11 @@ template <int MODE, int BKIND, bool VEC>
 __global__ __launch_bounds__(256) void gemmx_rows_kernel(const GXGroup g_byval) {
   KERNARG_IN_PLACE(GXGroup);
   constexpr int NA = Planes<MODE>::A, NB = Planes<MODE>::W;
-  const GXP& P = g.p[blockIdx.z];
-  const int m0 = blockIdx.x * GX_T, n0 = blockIdx.y * GX_T;
-  if (m0 >= P.M || n0 >= P.N) return;
+  const int pi = flat_problem(g, (int)blockIdx.x);
+  const GXP& P = g.p[pi];
+  const int local = (int)blockIdx.x - g.woff[pi], tiles_n = (P.N + GX_T - 1) / GX_T;
+  const int mt = local / tiles_n;
+  const int m0 = mt * GX_T, n0 = (local - mt * tiles_n) * GX_T;
   __shared__ __attribute__((aligned(16))) __bf16 As[2][NA * GX_ROW];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NB * GX_ROW];
   const int wave = threadIdx.x >> 6;
@@ -405,12 +419,13 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gemmx_tn_kernel(const GXGroup g_byval) {
   KERNARG_IN_PLACE(GXGroup);
   constexpr int NA = Planes<MODE>::A;  // both operands are activations
-  int pi = 0;
-  while (pi + 1 < g.n && (int)blockIdx.z >= g.zoff[pi + 1]) ++pi;
+  const int pi = flat_problem(g, (int)blockIdx.x);
   const GXP& P = g.p[pi];
-  const int m0 = blockIdx.x * GX_T, n0 = blockIdx.y * GX_T;
-  if (m0 >= P.M || n0 >= P.N) return;
-  const int bz = (int)blockIdx.z - g.zoff[pi];
+  const int local = (int)blockIdx.x - g.woff[pi], tiles_n = (P.N + GX_T - 1) / GX_T;
+  const int tiles = ((P.M + GX_T - 1) / GX_T) * tiles_n;
+  const int bz = local / tiles, tile = local - bz * tiles;  // tile fastest: the splits of a problem start together
+  const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+  const int m0 = mt * GX_T, n0 = nt * GX_T;
   __shared__ __attribute__((aligned(16))) __bf16 As[2][NA * GX_ROW];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NA * GX_ROW];
   const int wave = threadIdx.x >> 6;
@@ -422,8 +437,8 @@ __global__ __launch_bounds__(256) void gemmx_tn_kernel(const GXGroup g_byval) {
   const int s_beg = bz * P.steps_per_split;
   const int s_end = min(total, s_beg + P.steps_per_split);
   if (s_beg >= s_end) return;
-  const bool csA = P.kind == 3 && P.cs != nullptr && blockIdx.y == 0;
-  const bool csB = P.kind == 2 && P.cs != nullptr && blockIdx.x == 0;
+  const bool csA = P.kind == 3 && P.cs != nullptr && nt == 0;
+  const bool csB = P.kind == 2 && P.cs != nullptr && mt == 0;
   LoaderKS<NA> la, lb;
   la.init(P.A, s_beg * GX_BK);
   lb.init(P.B, s_beg * GX_BK);
@@ -678,11 +693,13 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
   static thread_local GXGroup G;
   for (int kind = 0; kind < 2; ++kind) {
     memset(&G, 0, sizeof G);
-    int maxm = 0, maxn = 0, big = 0, direct_ok = 1, wide_ok = 1, vec_ok = 1;
+    int maxm = 0, maxn = 0, big = 0, direct_ok = 1, wide_ok = 1, vec_ok = 1, wg = 0;
     double flops = 0, bytes = 0;
     for (int i = 0; i < n; ++i) {
       if (d[i].kind != kind || d[i].M <= 0 || d[i].N <= 0) continue;
-      GXP& P = G.p[G.n++];
+      GXP& P = G.p[G.n];
+      G.woff[G.n++] = wg;
+      wg += eqf_cdiv(d[i].M, GX_T) * eqf_cdiv(d[i].N, GX_T);
       P.A = {d[i].A, d[i].ra.d, d[i].ra.ld, d[i].ra.inner};
       P.B = {d[i].B, 1, d[i].ldb, 0};
       P.C = {d[i].C, d[i].rc.d, d[i].rc.ld, d[i].rc.inner};
@@ -704,7 +721,8 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
     // MLPs): the LDS-tiled kernel.  Timed under different names.
     const bool direct = !big && direct_ok && !g_gemmx_no_direct;
     const bool wide = kind == 1 && wide_ok && !g_gemmx_no_wide;
-    dim3 grid(direct ? 2 * maxm : maxm, wide ? 1 : (direct ? 2 * maxn : maxn), G.n);
+    for (int i = G.n; i <= GX_MAXP; ++i) G.woff[i] = i == G.n ? wg : INT_MAX;
+    const dim3 grid = wide ? dim3(maxm, 1, G.n) : direct ? dim3(2 * maxm, 2 * maxn, G.n) : dim3(wg, 1, 1);
     const int pid = eqf_prof_begin(kind == 0 ? (big ? "gemmx_group_kn_edge" : "gemmx_group_kn_node")
                                              : (big ? "gemmx_group_nk_edge" : "gemmx_group_nk_node"), st, flops, bytes);
 #define GX_ROWS(M_)                                                                                              \
@@ -731,7 +749,7 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
   }
   {
     memset(&G, 0, sizeof G);
-    int maxm = 0, maxn = 0, z = 0, big = 0, zd = 0;
+    int maxm = 0, maxn = 0, z = 0, big = 0, zd = 0, wg = 0;
     int zoff_d[GX_MAXP + 1];
     double flops = 0, bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -755,6 +773,8 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
       ksplit = eqf_cdiv(total_steps, P.steps_per_split);
       G.zoff[G.n] = z;
       z += ksplit;
+      G.woff[G.n] = wg;
+      wg += tiles * ksplit;
       zoff_d[G.n] = zd;
       zd += eqf_cdiv(P.K, GD_KC);
       G.n++;
@@ -771,7 +791,8 @@ int eqf_gemmx_group(const eqf_gemm_desc* d, int n, int mode, void* stream) {
         zoff_d[G.n] = zd;
         for (int i = 0; i <= G.n; ++i) G.zoff[i] = zoff_d[i];
       }
-      dim3 grid(direct ? 2 * maxm : maxm, direct ? 2 * maxn : maxn, direct ? zd : z);
+      for (int i = G.n; i <= GX_MAXP; ++i) G.woff[i] = i == G.n ? wg : INT_MAX;
+      const dim3 grid = direct ? dim3(2 * maxm, 2 * maxn, zd) : dim3(wg, 1, 1);
       const int pid = eqf_prof_begin(big ? "gemmx_group_tn_edge" : "gemmx_group_tn_node", st, flops, bytes);
       if (direct) {
         if (mode == 0) hipLaunchKernelGGL((gemmx_tn_direct_kernel<0>), grid, dim3(64), 0, st, G);
