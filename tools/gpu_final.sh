@@ -2,9 +2,9 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/${1:-r04_p}
+OUT=gpurun_out/${1:-rX}
 mkdir -p $OUT
-bash tools/gpu_profile.sh ${1:-r04_p} > $OUT/profile_script.log 2>&1
+bash tools/gpu_profile.sh ${1:-rX} > $OUT/profile_script.log 2>&1
 tail -5 $OUT/pmc_summary.txt
 head -42 $OUT/kernel_stats.txt | cut -c1-100,112-160
 python - <<PY

@@ -1,7 +1,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/${1:-r04_ac}
+OUT=gpurun_out/${1:-rX}
 mkdir -p $OUT
 timeout 120 python tools/gemm_shapes.py split 2>&1 | grep "node\|edge" > $OUT/shapes.txt
 cat $OUT/shapes.txt
