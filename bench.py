@@ -38,8 +38,7 @@ def parse():
     ap.add_argument("--atoms", type=int, default=18)
     ap.add_argument("--side", type=float, default=6.5, help="cube edge of the synthetic molecules (6.5 -> ~200 edges)")
     ap.add_argument("--dominant", default="",
-                    help="kernel-name substring timed with HIP events for the roofline line ('' = every matrix-core "
-                         "kernel; the one with the largest total time is reported)")
+                    help="kernel-name substring timed with HIP events for the roofline line (default: the dominant SeparableFCTP kernel, picked by one untimed step after the warm-up)")
     ap.add_argument("--cpu-molecules", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-cpu-full-batch", dest="cpu_full_batch", action="store_false",
@@ -370,6 +369,17 @@ def measure(args, dev, rank, world, workload, mode, steps, warmup, regions=("sfc
 
     for _ in range(warmup):
         step()
+    regions = list(regions)
+    if regions and regions[0] == "auto":
+        # one more untimed step with events on the SeparableFCTP kernels picks the dominant one; the timed region then carries
+        # events on THAT kernel only (every event pair is a dependency between consecutive launches: events on all 39
+        # SeparableFCTP launches of a QM9 step cost ~2 % of the step, `spread` [0] vs [2] of round 4)
+        lib.prof_enable("sfc")  # sfcx_* (split / bf16 modes) and sfc_* (fp32 mode)
+        step()
+        torch.cuda.synchronize()
+        first = lib.prof_report()
+        lib.prof_enable(None)
+        regions[0] = max(first, key=lambda k: first[k]["total_ms"]) if first else ""
     out = []
     loss = None
     for flt in regions:
@@ -385,7 +395,7 @@ def measure(args, dev, rank, world, workload, mode, steps, warmup, regions=("sfc
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         if world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        out.append((t.item(), prof))
+        out.append((t.item(), prof, flt))
     loss = float(loss.item())
     ops.set_matrix_mode(prev)
     return wl, out, loss
@@ -398,7 +408,7 @@ def sub_record(args, dev, workload, mode, steps=10, warmup=3):
         a2 = argparse.Namespace(**vars(args))
         a2.batch, a2.atoms, a2.side = 128, 18, 6.5
         wl, regs, loss = measure(a2, dev, 0, 1, workload, mode, steps, warmup, regions=("",))
-        dt, prof = regs[0]
+        dt, prof, _ = regs[0]
         rec = {"workload": workload, "matrix_mode": mode, "dtype": "bf16" if mode == "bf16" else "f32",
                "model": wl["model_name"], "value": wl["units"] * steps / dt, "unit": WORKLOADS[workload]["unit"],
                "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "units_per_step": wl["units"],
@@ -441,13 +451,14 @@ def main():
     # (equiformer_amd/ops.py: set_deferred_weight_gradients; FlatGradAllReduce switches it off again for N > 1)
     ops.set_deferred_weight_gradients(True)
 
-    # Region 1 is THE timed region of the contract (W warm-up steps, then exactly K steps): HIP events on the SeparableFCTP
-    # kernels only (the dominant kernel is one of them; `--dominant` overrides).  Regions 2 and 3 repeat the same K steps for the
+    # Region 1 is THE timed region of the contract (W warm-up steps, then exactly K steps): HIP events on the launches of the
+    # dominant kernel only (picked among the SeparableFCTP kernels by one profiled, untimed step after the warm-up; `--dominant`
+    # overrides).  Regions 2 and 3 repeat the same K steps for the
     # run-to-run spread: 2 with events on every matrix-core kernel (figures of the other kernels), 3 with no events at all.
-    first = args.dominant if args.dominant else "sfcx"
+    first = args.dominant if args.dominant else "auto"
     regions = (first, "", None) if args.repeats >= 3 else ((first, "") if args.repeats == 2 else (first,))
     wl, regs, loss = measure(args, dev, rank, world, args.workload, args.matrix_mode, args.steps, args.warmup, regions)
-    dt, prof = regs[0]
+    dt, prof, flt0 = regs[0]
     n_nodes, n_edges = wl["nodes"], wl["edges"]
 
     if rank == 0:
@@ -473,10 +484,10 @@ def main():
                 "arithmetic": ARITHMETIC[args.matrix_mode],
             },
         }
-        vals = [wl["units"] * world * args.steps / d for d, _ in regs]
+        vals = [wl["units"] * world * args.steps / d for d, _, _ in regs]
         out["spread"] = {"values": vals, "min": min(vals), "max": max(vals),
                          "note": "the same %d steps timed %d times back to back in this process: [0] = `value` (HIP events on the "
-                                 "SeparableFCTP kernels), [1] events on every matrix-core launch, [2] no events" % (args.steps, len(vals))}
+                                 "launches of `%s`), [1] events on every matrix-core launch, [2] no events" % (args.steps, len(vals), flt0)}
         rf = roofline_of(prof, dt, args.matrix_mode)
         allprof = regs[1][1] if len(regs) > 1 else prof
         if rf is not None:
