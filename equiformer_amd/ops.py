@@ -473,6 +473,7 @@ def _from_alias(a):
 def _flush_wgrads():
     entries = list(_deferred)
     del _deferred[:]
+    _deferred_task[0] = -1
     descs = []
     for (w, b, x, dy, spec, fused_b, aw, ab) in entries:
         # where the gradient lives now: the zero tensor backward() returned -- adopted as .grad by AccumulateGrad, or captured
@@ -499,8 +500,17 @@ def _can_defer(*params):
             and all(p is None or (p.is_leaf and p.requires_grad and p.grad is None) for p in params))
 
 
+_deferred_task = [-1]
+
+
 def _defer_lin_wgrad(w, b, x, dy, spec, fused_b, dw, db):
-    if not _deferred:
+    # one callback per backward pass (graph task).  Entries left behind by a pass that did not reach its callbacks -- an exception
+    # inside backward -- belong to gradients nobody will read: dropped, so that they can neither be launched into recycled
+    # memory nor keep this pass from queueing its own callback.
+    task = torch._C._current_graph_task_id()
+    if task != _deferred_task[0]:
+        del _deferred[:]
+        _deferred_task[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
     _deferred.append((w, b, x, dy, spec, fused_b, _alias(dw), _alias(db) if fused_b else None))
 
