@@ -63,13 +63,19 @@ class GraphAttentionTransformerMD17(_Trunk):
         else:
             raise ValueError
 
+    # The reference builds the forces with create_graph=True in every mode (graph_attention_transformer_md17.py:318-325).
+    # Here the differentiable (second-order) force pass runs in training mode only -- evaluation gets the plain first-order
+    # kernels, 3-4x cheaper -- unless this switch asks for the reference's behaviour in eval mode as well (forces that can be
+    # differentiated again, e.g. for a force-loss gradient on a validation batch).
+    differentiable_forces_in_eval = False
+
     @torch.enable_grad()
     def forward(self, node_atom, pos, batch):
         pos = pos.to(torch.float32).contiguous().requires_grad_(True)
         graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=1000)
         atom_embedding, _, _ = self.atom_embed(node_atom)
         trainable = any(p.requires_grad for p in self.parameters())
-        second_order = self.training and trainable
+        second_order = (self.training or self.differentiable_forces_in_eval) and trainable
         self.__dict__["_second_order_pass"] = second_order  # read by _trunk_forward (radial bank: first-order only)
         energy = self._trunk_forward(atom_embedding, pos, graph)
         if self.scale is not None:

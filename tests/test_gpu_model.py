@@ -245,6 +245,41 @@ def test_md17_force_loss_second_order_gradients(small):
     assert worst[1] < 1e-4, worst
 
 
+def test_md17_differentiable_forces_in_eval_mode():
+    """The reference's forces carry a graph in every mode (create_graph=True, ..._md17.py:318-325); the product's do in training
+    mode and, on request, in eval mode: same energies / forces as the plain eval pass, and the force-loss gradient equals the
+    training-mode one (no dropout in these models)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+    from weights import fill_deterministic
+    from equiformer_amd.nets.graph_attention_transformer_md17 import GraphAttentionTransformerMD17
+    from equiformer_amd.synthetic import md17_aspirin_batch
+    dev = _dev()
+    kw = dict(irreps_in="64x0e", max_radius=5.0, number_of_basis=32, basis_type="exp", **mg.SMALL_L2)
+    mod = fill_deterministic(GraphAttentionTransformerMD17(**kw), 12).to(dev)
+    d = md17_aspirin_batch(2, seed=3)
+    z, pos, batch = d["z"].to(dev), d["pos"].to(dev), d["batch"].to(dev)
+    B = torch.randn(42, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    mod.eval()
+    E0, F0 = mod(z, pos, batch)
+    assert not F0.requires_grad  # default: first-order evaluation
+    mod.differentiable_forces_in_eval = True
+    E1, F1 = mod(z, pos, batch)
+    assert F1.requires_grad
+    assert _rel(E1, E0) < 1e-5 and _rel(F1, F0) < 1e-4  # two kernel paths (radial bank vs per-module radial MLPs)
+    g1 = torch.autograd.grad((B * F1).sum(), list(mod.parameters()), allow_unused=True)
+    mod.differentiable_forces_in_eval = False
+    mod.train()
+    _, Ft = mod(z, pos, batch)
+    gt = torch.autograd.grad((B * Ft).sum(), list(mod.parameters()), allow_unused=True)
+    for (n, _), a, b in zip(mod.named_parameters(), g1, gt):
+        assert (a is None) == (b is None), n
+        if a is not None and b.abs().max() > 0:
+            assert _rel(a, b) < 1e-5, n
+
+
 def test_md17_l3_full_size_force_loss_gradients():
     """BASELINE config #4 at full size: the registered L_max = 3 MD17 model (graph_attention_transformer_nonlinear_exp_l3_md17,
     5 500 865 parameters; reference: nets/graph_attention_transformer_md17.py:426-442 with the create_graph forces of :318-325)
