@@ -384,6 +384,7 @@ def measure(args, dev, rank, world, workload, mode, steps, warmup, regions=("sfc
     loss = None
     for flt in regions:
         lib.prof_enable(flt)
+        ops.deferred_weight_gradient_stats(reset=True)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -396,6 +397,7 @@ def measure(args, dev, rank, world, workload, mode, steps, warmup, regions=("sfc
         if world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         out.append((t.item(), prof, flt))
+        wl["deferred_weight_gradients"] = dict(ops.deferred_weight_gradient_stats(), steps=steps)
     loss = float(loss.item())
     ops.set_matrix_mode(prev)
     return wl, out, loss
@@ -427,8 +429,27 @@ def sub_record(args, dev, workload, mode, steps=10, warmup=3):
         torch.cuda.empty_cache()
 
 
+def _self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: re-run this command as N ranks under torch.distributed.run (one process per
+    GPU, 127.0.0.1 rendezvous on a free port); rank 0 of the child job prints the JSON line on this process's stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL / cross-process HIP memory)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_spawn(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -447,9 +468,9 @@ def main():
     from equiformer_amd import lib, ops
     lib.load()
     ops._overlap_wgrad[0] = args.overlap_wgrad
-    # a loss.backward() training loop: the node-row weight gradients go out in a few grouped launches when backward ends
-    # (equiformer_amd/ops.py: set_deferred_weight_gradients; FlatGradAllReduce switches it off again for N > 1)
-    ops.set_deferred_weight_gradients(True)
+    # (a loss.backward() training loop: the node-row weight gradients go out in a few grouped launches when backward ends --
+    # the library default, equiformer_amd/ops.py; FlatGradAllReduce's tail hook flushes what is queued before its collective,
+    # so the N > 1 step is the same step.  `config.deferred_weight_gradients` records what the timed region did.)
 
     # Region 1 is THE timed region of the contract (W warm-up steps, then exactly K steps): HIP events on the launches of the
     # dominant kernel only (picked among the SeparableFCTP kernels by one profiled, untimed step after the warm-up; `--dominant`
@@ -482,6 +503,9 @@ def main():
                 "final_loss": loss,
                 "matrix_mode": args.matrix_mode,
                 "arithmetic": ARITHMETIC[args.matrix_mode],
+                # node-row weight gradients queued during backward and launched in groups (library default; with N > 1 the
+                # reducer's hook flushes them before its collective): problems queued / grouped launches in the last region
+                "deferred_weight_gradients": wl.get("deferred_weight_gradients"),
             },
         }
         vals = [wl["units"] * world * args.steps / d for d, _, _ in regs]

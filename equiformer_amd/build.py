@@ -82,7 +82,10 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + dev + ["-c", os.path.join(CSRC, s), "-o", o]
+        extra = list(EXTRA_FLAGS.get(s, []))
+        if s == "rowops.hip":  # eqf_version() lives there and reports the hash of the sources of THIS build
+            extra.append('-DEQF_SOURCE_HASH="%s"' % source_hash())
+        cmd = [hipcc] + FLAGS + extra + dev + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

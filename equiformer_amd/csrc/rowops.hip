@@ -601,7 +601,12 @@ __global__ __launch_bounds__(256) void fold_bwd_kernel(const float* __restrict__
 
 extern "C" {
 
-const char* eqf_version(void) { return "equiformer_hip 0.1 gfx950"; }
+// EQF_SOURCE_HASH = equiformer_amd.build.source_hash() of the sources this object was compiled from (build.py passes it):
+// lib.load() compares it with the hash of the sources beside the library and refuses a stale binary.
+#ifndef EQF_SOURCE_HASH
+#define EQF_SOURCE_HASH "unknown"
+#endif
+const char* eqf_version(void) { return "equiformer_hip 0.1 gfx950 src=" EQF_SOURCE_HASH; }
 
 int eqf_add_layernorm_fwd(const float* x, const float* x2, float* xsum, const float* weight, const float* bias, float* y,
                           float* rstd, float* mean0, int rows, const eqf_irreps* irreps, float eps, void* stream) {

@@ -166,8 +166,36 @@ def load():
         fn = getattr(lib, name)  # AttributeError -> missing symbol, loud
         fn.restype = RESTYPES.get(name, c_int)
         fn.argtypes = argtypes
+    _check_build(lib)
     _lib = lib
     return lib
+
+
+def _check_build(lib):
+    """The library reports the hash of the sources it was compiled from (eqf_version: "... src=<hash>").  When the sources
+    sit beside it (a checkout, a gpurun snapshot) and their hash differs, the binary is stale: measurements and parity
+    claims would belong to other code.  EQF_ALLOW_STALE_LIB=1 turns the error into a warning (development builds)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if not os.path.isdir(csrc):
+        return
+    ver = lib.eqf_version().decode()
+    built = ver.split("src=")[-1] if "src=" in ver else "unknown"
+    from . import build as _build
+    want = _build.source_hash()
+    if built != want:
+        msg = ("libequiformer_hip.so was built from sources with hash %s, the sources beside it hash to %s -- rebuild with "
+               "`python -m equiformer_amd.build`" % (built, want))
+        if os.environ.get("EQF_ALLOW_STALE_LIB") == "1":
+            import warnings
+            warnings.warn(msg)
+        else:
+            raise HipLibraryError(msg)
+
+
+def built_hash():
+    """Hash of the sources the LOADED binary was compiled from."""
+    ver = version()
+    return ver.split("src=")[-1] if "src=" in ver else "unknown"
 
 
 def version():

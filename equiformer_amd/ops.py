@@ -7,6 +7,7 @@ reference's module tree.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -429,34 +430,57 @@ def _lin_wgrad_descs(x, dy, spec, dw, db=None):
 
 
 # Weight gradients of the node-row linears are not on backward's dependency chain: dW = x^T dy needs nothing that comes later
-# and nothing later needs dW.  Each of these launches costs 16-24 us whatever it computes (2 304 rows; profiles/r04), so a
-# training loop can ask for them to be queued during loss.backward() and launched TOGETHER when the autograd engine finishes the
-# pass (engine callback): 27 launches of 3 problems become 4 launches of <= 24.
+# and nothing later needs dW.  Each of these launches costs 16-24 us whatever it computes (2 304 rows; profiles/r04), so during
+# loss.backward() they are QUEUED and launched TOGETHER when the autograd engine finishes the pass (engine callback): 27 launches
+# of 3 problems become 4 launches of <= 24.  On by default (ops.set_deferred_weight_gradients(False) / EQF_DEFER_WGRAD=0 turn it
+# off); it only ever applies where it is provably safe:
 #
-#   ops.set_deferred_weight_gradients(True)        # OPT-IN (bench.py does)
-#
-# backward() then returns zero-initialised tensors as the gradients of LEAF parameters; AccumulateGrad makes them (or a sum
-# containing them) the parameter's .grad, and the deferred launch accumulates into whatever tensor the parameter's .grad IS when
-# the pass ends -- correct for loss.backward() in every case (one or several contributions per parameter, existing .grad).
-# With torch.autograd.grad(loss, parameters) the engine hands the zero tensor back instead of storing it; the launch still
-# lands in it as long as the parameter has ONE contribution in the pass, but a second contribution makes the engine sum
-# out of place and the queued one would be lost -- which is why this is opt-in, why it switches itself off for good once a
-# create_graph pass has been seen in the process (force-loss training gives every parameter several contributions), and why
-# FlatGradAllReduce switches it off (its backward hook ships gradients as soon as autograd has accumulated them).
-_defer_wgrad = [os.environ.get("EQF_DEFER_WGRAD", "") == "1"]
-_seen_create_graph = [False]
-_deferred = []
+#   * backward() returns a zero-initialised tensor as the gradient of a LEAF parameter; AccumulateGrad makes it (or a copy of it)
+#     the parameter's .grad, and the queued launch accumulates into whatever tensor the parameter's .grad IS when the pass ends;
+#   * only passes that ACCUMULATE into .grad qualify (`loss.backward()`): under torch.autograd.grad(loss, params) the engine
+#     captures gradients instead and sums several contributions of one parameter out of place, which would lose a queued one --
+#     `_accumulates_into_grad` asks the engine itself (the parameter's AccumulateGrad node will run in this graph task);
+#   * a create_graph pass (grad mode on inside backward) computes everything at once;
+#   * the queue belongs to ONE graph task: a nested / re-entrant backward (torch.utils.checkpoint, a Function that calls
+#     backward inside its backward) or a pass on another thread has its own queue and its own callback.  The queue object is owned
+#     by the engine callback's closure only (the module keeps a weak reference), so a pass that dies inside backward takes its
+#     entries with it: they can neither be launched into recycled memory nor block a later pass;
+#   * consumers that read gradients DURING backward (FlatGradAllReduce's tail hook, any post-accumulate-grad hook) call
+#     `flush_deferred_weight_gradients()` first: what is queued so far is launched (stream-ordered before whatever the hook
+#     enqueues next), the rest of the pass queues anew.
+
+_defer_wgrad = [os.environ.get("EQF_DEFER_WGRAD", "1") != "0"]
+_defer_stats = {"queued": 0, "flushes": 0}
+
+
+class _TaskQueue:
+    """queued weight-gradient problems of one graph task"""
+    __slots__ = ("entries", "__weakref__")
+
+    def __init__(self):
+        self.entries = []
+
+
+_task_queues = weakref.WeakValueDictionary()  # graph task id -> _TaskQueue (kept alive by that task's engine callback only)
 
 
 def note_create_graph():
-    """called by the create_graph branches of the operators' backward"""
-    _seen_create_graph[0] = True
+    """called by the create_graph branches of the operators' backward (kept for callers; deferral keys on the grad mode itself)"""
 
 
 def set_deferred_weight_gradients(on):
     prev = _defer_wgrad[0]
     _defer_wgrad[0] = bool(on)
     return prev
+
+
+def deferred_weight_gradient_stats(reset=False):
+    """{"queued": problems queued, "flushes": grouped launches} since the last reset: lets a caller (bench.py, the tests) state
+    whether the deferred path actually ran"""
+    out = dict(_defer_stats)
+    if reset:
+        _defer_stats["queued"] = _defer_stats["flushes"] = 0
+    return out
 
 
 def _alias(t):
@@ -470,14 +494,13 @@ def _from_alias(a):
     return torch.empty(0, dtype=torch.float32, device=dev).set_(stor, off, (n,))
 
 
-def _flush_wgrads():
-    entries = list(_deferred)
-    del _deferred[:]
-    _deferred_task[0] = -1
+def _launch_queue(q):
+    entries, q.entries = q.entries, []
     descs = []
     for (w, b, x, dy, spec, fused_b, aw, ab) in entries:
-        # where the gradient lives now: the zero tensor backward() returned -- adopted as .grad by AccumulateGrad, or captured
-        # by torch.autograd.grad (.grad still None) -- unless AccumulateGrad made a copy of it (then .grad is another tensor)
+        # where the gradient lives now: the zero tensor backward() returned -- adopted as .grad by AccumulateGrad, or still on
+        # its way to it (an early flush: AccumulateGrad then adopts or copies the FILLED tensor, stream-ordered) -- unless
+        # AccumulateGrad already made a copy of it (then .grad is another tensor and receives the launch)
         tw = _from_alias(aw)
         if w.grad is not None and w.grad.data_ptr() != tw.data_ptr():
             tw = w.grad.view(-1)
@@ -490,29 +513,49 @@ def _flush_wgrads():
             raise RuntimeError("deferred weight gradient: .grad must be a contiguous fp32 tensor")
         descs += _lin_wgrad_descs(x, dy, spec, tw, tb)
     if descs:
+        _defer_stats["flushes"] += 1
         _gemm_group(descs, _stream())
 
 
+def flush_deferred_weight_gradients():
+    """Launch what the CURRENT backward pass has queued so far (no-op outside a pass or with an empty queue).  For code that
+    consumes gradients during backward: gradient hooks, bucketed reducers."""
+    try:
+        task = torch._C._current_graph_task_id()
+    except Exception:
+        return
+    q = _task_queues.get(task)
+    if q is not None and q.entries:
+        _launch_queue(q)
+
+
+def _accumulates_into_grad(p):
+    """True iff this graph task will run the parameter's AccumulateGrad node, i.e. the pass is a .backward() that stores into
+    p.grad (torch.autograd.grad captures the gradient at that node instead: the engine refuses the question for such a leaf)"""
+    try:
+        return bool(torch._C._will_engine_execute_node(torch.autograd.graph.get_gradient_edge(p).node))
+    except RuntimeError:
+        return False
+
+
 def _can_defer(*params):
-    """plain first-order backward, leaf parameters without an existing .grad (an existing one is added to OUT of place or in
+    """plain first-order .backward(), leaf parameters without an existing .grad (an existing one is added to OUT of place or in
     place depending on the engine's mood: those gradients are computed at once)"""
-    return (_defer_wgrad[0] and not _seen_create_graph[0] and not torch.is_grad_enabled()
-            and all(p is None or (p.is_leaf and p.requires_grad and p.grad is None) for p in params))
-
-
-_deferred_task = [-1]
+    return (_defer_wgrad[0] and not torch.is_grad_enabled()
+            and all(p is None or (p.is_leaf and p.requires_grad and p.grad is None and _accumulates_into_grad(p))
+                    for p in params))
 
 
 def _defer_lin_wgrad(w, b, x, dy, spec, fused_b, dw, db):
-    # one callback per backward pass (graph task).  Entries left behind by a pass that did not reach its callbacks -- an exception
-    # inside backward -- belong to gradients nobody will read: dropped, so that they can neither be launched into recycled
-    # memory nor keep this pass from queueing its own callback.
     task = torch._C._current_graph_task_id()
-    if task != _deferred_task[0]:
-        del _deferred[:]
-        _deferred_task[0] = task
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
-    _deferred.append((w, b, x, dy, spec, fused_b, _alias(dw), _alias(db) if fused_b else None))
+    q = _task_queues.get(task)
+    if q is None:
+        q = _TaskQueue()
+        _task_queues[task] = q
+        # the closure is the ONLY strong reference to the queue: it lives exactly as long as the graph task does
+        torch.autograd.Variable._execution_engine.queue_callback(lambda q=q: _launch_queue(q))
+    q.entries.append((w, b, x, dy, spec, fused_b, _alias(dw), _alias(db) if fused_b else None))
+    _defer_stats["queued"] += 1
 
 
 def _lin_wgrad(x, dy, spec, dw, db=None):

@@ -77,11 +77,6 @@ class FlatGradAllReduce:
             k = min(max(k, 1), len(self.params) - 1)
             self.split = k
             self._handles = [p.register_post_accumulate_grad_hook(self._on_tail_grad) for p in self.params[k:]]
-            if self._active():
-                # the hook ships gradients as soon as autograd has accumulated them: weight gradients that are only queued at
-                # that point (equiformer_amd.ops: deferred grouped launches of the node-row linears) must not exist then
-                from . import ops as _ops
-                _ops.set_deferred_weight_gradients(False)
 
     # ---------------------------------------------------------------------------------------------------------------
     def world_size(self):
@@ -142,6 +137,11 @@ class FlatGradAllReduce:
         self._arrived.add(id(param))
         if len(self._arrived) < len(self.params) - self.split:
             return
+        # the hook ships gradients as soon as autograd has accumulated them: weight gradients that are only QUEUED at this point
+        # (equiformer_amd.ops: deferred grouped launches of the node-row linears) are launched first -- stream-ordered before the
+        # pack and the collective; what the rest of backward queues goes out when the pass ends, before reduce()
+        from . import ops as _ops
+        _ops.flush_deferred_weight_gradients()
         self._pack(self.split, len(self.params))
         tail = self.flat[self.offsets[self.split]:]
         self._pending = self._all_reduce(tail, async_op=True)

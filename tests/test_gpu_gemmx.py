@@ -175,23 +175,22 @@ def test_deferred_weight_gradients_equal_immediate_ones():
         return (m(None, d["pos"], d["batch"], d["z"]).squeeze() - d["y"]).abs().mean()
 
     res = {}
-    assert not ops._seen_create_graph[0] or True  # (a create_graph pass earlier in the process switches the deferral off:
-    seen = ops._seen_create_graph[0]              #  reset for this test, restored below)
-    ops._seen_create_graph[0] = False
     for on in (False, True):
         prev = ops.set_deferred_weight_gradients(on)
         try:
             for p in params:
                 p.grad = None
+            ops.deferred_weight_gradient_stats(reset=True)
             loss().backward()
+            stats = ops.deferred_weight_gradient_stats()
+            assert (stats["queued"] > 0 and 0 < stats["flushes"] <= 8) if on else stats["queued"] == 0, stats
             res[on, "backward"] = [None if p.grad is None else p.grad.clone() for p in params]
             res[on, "grad"] = list(torch.autograd.grad(loss(), params, allow_unused=True))
             loss().backward()  # second pass onto existing .grad: 2 x the gradient
             res[on, "twice"] = [None if p.grad is None else p.grad.clone() for p in params]
         finally:
             ops.set_deferred_weight_gradients(prev)
-    ops._seen_create_graph[0] = seen
-    assert not ops._deferred
+    assert not any(q.entries for q in ops._task_queues.values())
     for key in ("backward", "grad", "twice"):
         for a, b in zip(res[True, key], res[False, key]):
             assert (a is None) == (b is None)
