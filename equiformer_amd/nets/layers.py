@@ -571,7 +571,7 @@ class GraphAttention(nn.Module):
         sv = self.sep_value
         gt = sa.gate
         if (self.use_fused is True and isinstance(gt, Gate) and sv.gate is None
-                and ops.sep_fctp_gated_ok(sv.sfc_spec, value.shape[1], gt.S, gt.gated_layout)):
+                and ops.sep_fctp_gated_ok(sv.sfc_spec, value.shape[1], gt.S, gt.gated_layout, E=value.shape[0])):
             # the gate is folded into sep_value's kernels: its output rows are never written (csrc/sfcx.hip, *_gated)
             w2 = ectx.radial(sv.dtp_rad) if sv.dtp_rad is not None else None
             value = ops.sep_fctp_gated(value, ectx.coupling(sv.dtp.table), w2, sv.flat_weight(), sv.lin._bias(), sv.sfc_spec,

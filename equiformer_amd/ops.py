@@ -1897,8 +1897,13 @@ class SfcSpec:
         self._x_mask = {}
         self._packed_numel = {}
 
-    def x_mask(self, mode):
-        """bit 0 forward, bit 1 data gradient, bit 2 weight gradient of csrc/sfcx.hip can serve this operator in `mode`"""
+    def x_mask(self, mode, E=None):
+        """bit 0 forward, bit 1 data gradient, bit 2 weight gradient of csrc/sfcx.hip can serve this operator in `mode`.
+        E: rows of the launch -- the split-precision kernels address every per-edge tensor with 32-bit element offsets
+        (`fits32` in csrc/sfcx_common.h); a launch whose widest tensor reaches 2^31 elements is served by the exact-fp32
+        kernels instead (the planners' verdict is cached for a nominal E, so the size limit is re-checked here)."""
+        if E is not None and int(E) * self._widest_row() >= (1 << 31):
+            return 0
         m = self._x_mask.get(mode)
         if m is None:
             m = 0
@@ -1908,6 +1913,10 @@ class SfcSpec:
                     raise lib.HipLibraryError("eqf_sfcx_supported failed with code %d" % m)
             self._x_mask[mode] = m
         return m
+
+    def _widest_row(self):
+        # x (+ the gate scalars of a folded gate: at most as many again), w, coupling, out1, out2 rows
+        return max(2 * self.table.layout_in.dim, self.table.weight_numel, self.table.m_numel, self.out_layout.dim, self.n2, 1)
 
     @property
     def x_ok(self):
@@ -1961,10 +1970,10 @@ def _side_stream(dev):
     return st
 
 
-def _sfc_mode(spec):
-    """mode code of the split-precision kernels for this operator, None = exact-fp32 kernels"""
+def _sfc_mode(spec, E=None):
+    """mode code of the split-precision kernels for this operator (and launch size), None = exact-fp32 kernels"""
     m = _MATRIX_MODES[_matrix_mode[0]]
-    return m if (m is not None and spec.supported and spec.x_mask(m) != 0) else None
+    return m if (m is not None and spec.supported and spec.x_mask(m, E) != 0) else None
 
 
 def _sfc_Wl(weight, spec):
@@ -2098,7 +2107,7 @@ class _SepFctp(Function):
         _chk(x, coupling, w, weight, bias, weight2, bias2)
         assert weight.numel() == spec.weight_numel and (weight2 is None) == (spec.n2 == 0)
         assert weight2 is None or weight2.numel() == spec.weight2_numel
-        ctx.mode = mode = _sfc_mode(spec)
+        ctx.mode = mode = _sfc_mode(spec, x.shape[0])
         # the planes are saved for the data gradient (a raw attribute: the tensor is not part of the autograd graph; like
         # any saved tensor they describe the weights AT FORWARD TIME -- an in-place weight update between forward and backward,
         # which FlatAdamW's raw-pointer writes would not even trip autograd's version check on, is not supported)
@@ -2211,8 +2220,8 @@ class _SepFctpGated(Function):
         S, gated_layout, c_silu, c_sig = gate
         G = sum(m for m, _ in gated_layout.segs)
         assert spec.n2 == 0 and x_raw.shape[1] == S + G + gated_layout.dim and weight.numel() == spec.weight_numel
-        mode = _sfc_mode(spec)
-        assert mode is not None and spec.x_mask(mode) == 7
+        mode = _sfc_mode(spec, x_raw.shape[0])
+        assert mode is not None and spec.x_mask(mode, x_raw.shape[0]) == 7
         ctx.mode, ctx.gate = mode, gate
         ctx.gin = lib.EqfGateIn(int(S), int(G), float(c_silu), float(c_sig))
         ctx.packed = _sfc_pack(weight, None, spec, mode)
@@ -2282,13 +2291,13 @@ class _SepFctpGated(Function):
 _fuse_gate = [os.environ.get("EQF_NO_GATE_FUSION", "") == ""]  # A/B switch: False = separate gate kernels in front of sep_value
 
 
-def sep_fctp_gated_ok(spec, x_raw_dim, S, gated_layout):
+def sep_fctp_gated_ok(spec, x_raw_dim, S, gated_layout, E=None):
     """the gate can be folded into this operator's kernels: split-precision kernels for all three launches, no second consumer,
     degrees <= 2, scalar segment = the first S channels"""
     if not _fuse_gate[0] or spec.n2 != 0 or not spec.supported:
         return False
-    mode = _sfc_mode(spec)
-    if mode is None or spec.x_mask(mode) != 7:
+    mode = _sfc_mode(spec, E)
+    if mode is None or spec.x_mask(mode, E) != 7:
         return False
     if max([p["l1"] for p in spec.table.paths] + [l3 for l3, _, _, _ in spec.degs]) > 2:
         return False

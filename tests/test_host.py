@@ -316,3 +316,22 @@ def test_model_can_be_deep_copied_and_pickled():
     buf = io.BytesIO()
     torch.save(m, buf)
     assert buf.tell() > 0
+
+
+def test_split_precision_kernels_are_not_chosen_for_launches_beyond_32_bit_offsets():
+    """eqf_sfcx_supported plans with a nominal E, the kernels index per-edge tensors with 32-bit element offsets: a
+    launch whose widest tensor reaches 2^31 elements must be routed to the exact-fp32 kernels, not fail in the planner."""
+    from equiformer_amd import ops
+    from equiformer_amd.layout import DtpTable, RowLayout
+    table = DtpTable("128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "128x0e+64x1e+32x2e")
+    spec = ops.SfcSpec(table, RowLayout("224x0e+64x1e+32x2e"), n2=128)
+    assert spec.x_mask(0) == 7 and spec.x_mask(0, 25354) == 7
+    big = (1 << 31) // spec._widest_row() + 1
+    assert spec.x_mask(0, big) == 0 and spec.x_mask(0, big - 2) == 7
+    prev = ops.set_matrix_mode("split")
+    try:
+        assert ops._sfc_mode(spec, 25354) == 0 and ops._sfc_mode(spec, big) is None
+        assert not ops.sep_fctp_gated_ok(ops.SfcSpec(table, RowLayout("128x0e+64x1e+32x2e")), 576, 128,
+                                         RowLayout("64x1e+32x2e"), E=big)
+    finally:
+        ops.set_matrix_mode(prev)
