@@ -70,18 +70,29 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not _stale():
+def build(force=False, verbose=True, out=None, extra_flags=(), only=None):
+    """out / extra_flags: an A/B VARIANT of the library (development: `python -m equiformer_amd.build --variant NAME -DEQF_X=0`
+    writes equiformer_amd/libequiformer_hip_NAME.so, objects under csrc/.variant_NAME/; loaded with EQF_LIB_VARIANT=NAME)."""
+    if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "hipcc")
     # development builds: EQF_EXTRA_FLAGS="-DEQF_DEV_SWITCHES=1" (phase switches / cycle counters inside the sfc and gemm
     # kernels, tools/sfc_exp.py, tools/gemm_exp.py) or "-DEQF_XTRACE=1" (in-kernel clock samples, tools/sfcx_trace.py)
-    dev = os.environ.get("EQF_EXTRA_FLAGS", "").split()
+    dev = os.environ.get("EQF_EXTRA_FLAGS", "").split() + list(extra_flags)
     objs = []
     procs = []
+    objdir = CSRC
+    if out is not None:
+        objdir = os.path.join(CSRC, ".variant_" + os.path.basename(out).replace("libequiformer_hip_", "").replace(".so", ""))
+        os.makedirs(objdir, exist_ok=True)
     for s in SOURCES:
-        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
+        if only is not None and s not in only:
+            base = os.path.join(CSRC, s.replace(".hip", ".o"))
+            if os.path.exists(base):  # (variant builds: the product build's objects of untouched sources are reused)
+                objs[-1] = base
+                continue
         extra = list(EXTRA_FLAGS.get(s, []))
         if s == "rowops.hip":  # eqf_version() lives there and reports the hash of the sources of THIS build
             extra.append('-DEQF_SOURCE_HASH="%s"' % source_hash())
@@ -92,13 +103,23 @@ def build(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    target = out or LIB
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        name = sys.argv[i + 1]
+        rest = [a for a in sys.argv[i + 2:] if a != "--force"]
+        only = [a[len("--only="):] for a in rest if a.startswith("--only=")]
+        flags = [a for a in rest if not a.startswith("--only=")]
+        print(build(force=True, out=os.path.join(HERE, "libequiformer_hip_%s.so" % name), extra_flags=flags,
+                    only=only[0].split(",") if only else None))
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libequiformer_hip.so")
+if os.environ.get("EQF_LIB_VARIANT"):  # development A/B builds of the same sources (equiformer_amd/build.py --variant NAME ...)
+    LIB_PATH = os.path.join(_HERE, "libequiformer_hip_%s.so" % os.environ["EQF_LIB_VARIANT"])
 
 EQF_MAX_SEG = 8
 EQF_MAX_PATHS = 72
