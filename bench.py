@@ -56,6 +56,9 @@ def parse():
                          "energy + forces, force-loss train step through the second-order backward, 8 / 5 frames per GPU as "
                          "the reference scripts) | oc20 (config #5: IS2RE l1_256_nonlinear, 16 structures per GPU, periodic "
                          "graph built on the device)")
+    ap.add_argument("--diag-static-graph", action="store_true",
+                    help="DIAGNOSTIC, not a valid measurement: build the radius graph once outside the step (no host "
+                         "synchronisation inside the step) -- shows how much of the step is the graph's sync bubble")
     ap.add_argument("--matrix-mode", default="split", choices=["split", "bf16", "fp32", "split6"],
                     help="arithmetic of the fused SeparableFCTP matrix steps (equiformer_amd.ops.set_matrix_mode): split = "
                          "fp32 operands as bf16 planes on the bf16 matrix cores (fp32-class results, the headline); bf16 = "
@@ -159,10 +162,12 @@ def build_workload(args, dev, rank, world):
         model = nets.model_entrypoint(W["model"])(irreps_in="5x0e", radius=5.0, num_basis=128).to(dev).train()
         d = {k: v.to(dev) for k, v in qm9_like_batch(args.batch, args.atoms, side=args.side, seed=1000 + rank).items()}
 
-        def fwd_loss():
-            pred = model(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"])
-            return (pred.squeeze() - d["y"]).abs().mean()  # L1Loss (main_qm9.py:188-189)
         g = EdgeGraph.from_radius(d["pos"], d["batch"], 5.0)
+        static_graph = g if getattr(args, "diag_static_graph", False) else None
+
+        def fwd_loss():
+            pred = model(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"], graph=static_graph)
+            return (pred.squeeze() - d["y"]).abs().mean()  # L1Loss (main_qm9.py:188-189)
         units = args.batch
         text = ("QM9 %s train step (radius graph + fwd + L1 + bwd + AdamW), %d molecules/GPU x %d atoms, r=5.0, "
                 "num_basis=128, alpha_drop=0.2" % (W["model"], args.batch, args.atoms))
@@ -538,6 +543,13 @@ def main():
             extra["scatter"] = {"kernel": "attn_fwd (segment softmax + aggregation)", "bound": "hbm", "achieved": gbps,
                                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                                 "avg_launch_ms": sc["total_ms"] / sc["launches"], "algorithmic_bytes_per_launch": byts}
+            pmc, note = _pmc_record()
+            if pmc is not None and "attn_fwd" in pmc:  # rocprofv3 FETCH_SIZE / WRITE_SIZE of this build (tools/gpu_profile.sh)
+                tb = pmc["attn_fwd"]["hbm_bytes_per_launch"]
+                extra["scatter"].update({"traffic": tb, "traffic_over_algorithmic": tb / byts,
+                                         "counter_gbps": tb * sc["launches"] / sc["total_ms"] / 1e6,
+                                         "counter_frac": tb * sc["launches"] / sc["total_ms"] / 1e6 / PEAK_HBM_GBPS,
+                                         "traffic_source": note})
         # the widest E-row GEMM with a memory A operand and an [N, K] weight = the radial MLP's last layer
         rad = [(n2, r2) for n2, r2 in allprof.items()
                if (n2.startswith("gemm_rows_") and n2.endswith("_mem_nk")) or n2 in ("gemmx_group_nk_edge", "gemm_group_nk")]
@@ -549,6 +561,14 @@ def main():
                                              "G x (64 -> 960); the last is 94 % of their flops)", "bound": "mfma", "achieved": tf,
                                    "peak": pk, "unit": "TFLOP/s", "frac": tf / pk, "frac_of_fp32_peak": tf / PEAK_F32_MFMA_TFLOPS,
                                    "avg_launch_ms": r2["total_ms"] / r2["launches"]}
+            pmc, note = _pmc_record()
+            if pmc is not None and "gemmx_rows_wide" in pmc:
+                # the last layer's own kernel (E x 64 -> 7 x 960): SQ_INSTS_MFMA per launch over its kernel-trace duration
+                w = pmc["gemmx_rows_wide"]
+                extra["radial_mlp"]["widest_layer_kernel"] = {
+                    "kernel": "gemmx_rows_wide_kernel", "mfma_insts_per_launch": w.get("mfma_insts_per_launch"),
+                    "avg_us_kernel_trace": w.get("avg_us_kernel_trace"), "mfma_busy": w.get("mfma_busy"),
+                    "hbm_bytes_per_launch": w.get("hbm_bytes_per_launch"), "traffic_source": note}
         # whole step against the HBM roofline of SURVEY 8d: 3.0 MB algorithmic bytes per molecule-step at E = 200
         if args.workload == "qm9":
             b_alg = 6 * (172800.0 + 1112.0 * n_edges / args.batch) + 0.29e6 + 0.33e6
@@ -563,7 +583,8 @@ def main():
             del wl, regs
             torch.cuda.empty_cache()
             subs = []
-            for wname, mode in (("qm9", "bf16"), ("oc20", "split"), ("md17_l2", "split"), ("md17_l3", "split")):
+            # (qm9 / fp32: exact-fp32 MFMA in every matrix step -- the like-for-like figure against the reference's --no-amp)
+            for wname, mode in (("qm9", "bf16"), ("qm9", "fp32"), ("oc20", "split"), ("md17_l2", "split"), ("md17_l3", "split")):
                 subs.append(sub_record(args, dev, wname, mode))
                 print("[bench] sub-record %s/%s: %s" % (wname, mode, {k: subs[-1].get(k) for k in ("value", "ms_per_step", "error")}),
                       file=sys.stderr, flush=True)

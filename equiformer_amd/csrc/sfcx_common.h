@@ -1,6 +1,6 @@
-// Pieces shared by the split-precision SeparableFCTP translation units (sfcx.hip: forward, weight gradient, first data-gradient
-// kernel; sfcx_bwd2.hip: the multi-wave data gradient): plane splitting, packed-weight layout, row-major tile I/O, the argument
-// tables of the data gradient and their planner.  Everything sits in an anonymous namespace: each unit gets its own copy.
+// Pieces of the split-precision SeparableFCTP kernels (sfcx.hip): plane splitting, packed-weight layout, row-major tile I/O, the
+// argument tables of the data gradient and their planner.  (A second translation unit, the multi-wave data gradient of round 4,
+// shared this header; it only ever reached parity with the one-wave kernel and was removed in round 5: DESIGN.md 3.1c.)
 #pragma once
 #include "common.h"
 #include "prof.h"
@@ -11,12 +11,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-namespace sfcx {
-// sfcx_bwd2.hip: the multi-wave data gradient (d_out planes shared through LDS).  EQF_E_UNSUPPORTED = nothing launched, use the
-// one-wave kernel of sfcx.hip.  plan_only: host-side verdict without a launch.
-int bwd2_launch(const sfc::SfcCommon& C, const eqf_dtp_paths* P, int mode, float* dx, float* dw, float* dM, const void* packed,
-                bool plan_only, void* stream);
-}  // namespace sfcx
 
 namespace {
 using namespace sfc;

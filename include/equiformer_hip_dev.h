@@ -36,8 +36,8 @@ int eqf_sfc_debug_buffer(void* device_u64x8);
  * numpy on these tables.  Returns the number of characters written or a negative error. */
 int eqf_sfcx_dev_plan(int kind, const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int E, int mode,
                       char* buf, int buflen);
-/* switches of the split-precision kernels: key 0 = data-gradient kernel (2 = the multi-wave kernel of csrc/sfcx_bwd2.hip where
- * the operator fits it; anything else = the one-wave kernel, the default) */
+/* switches of the split-precision kernels: none at present (returns EQF_E_BADARG); A/B measurements of these kernels use variant
+ * builds of the library (equiformer_amd/build.py --variant NAME -DEQF_...=...) */
 int eqf_sfcx_dev_set(int key, int value);
 /* csrc/gemmx.hip: key 0 = 0 selects the one-wave-per-tile kernels for node-row problems (default 1: LDS-tiled kernels for all) */
 int eqf_gemmx_dev_set(int key, int value);

@@ -50,7 +50,7 @@ def test_roofline_object_recomputes():
 
 
 def test_recorded_driver_style_line_is_self_consistent():
-    path = os.path.join(ROOT, "profiles", "r04", "r04_drv_bench_default.json")
+    path = os.path.join(ROOT, "profiles", "r04", "r04_drv_bench_default.json")  # (round 5 adds a ("qm9", "fp32") sub-record)
     d = json.loads(open(path).read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["unit"] == "molecules/s" and d["n_gpus"] == 1 and d["higher_is_better"] and d["scaling"] == "weak"

@@ -7,8 +7,13 @@
     gradients of the L1 training loss <= 1e-4 of the largest gradient entry of the tensor;
   * bit-equal energies for the same input twice.
 """
+import os
+import sys
+
 import pytest
 import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))  # fullsize.py (fixture format)
 
 from oracle import e3 as oe3
 from oracle import nets as onets
@@ -149,28 +154,28 @@ def test_qm9_full_batch_is_deterministic():
 def _full_batch_errors(mode):
     """The bench workload itself (reference: nets/graph_attention_transformer.py:864-899 with the model of :921-937,
     L1 loss of engine.py:71) against the oracle in fp64: energies of all 128 molecules and the gradient of every
-    parameter tensor, in matrix mode `mode`."""
+    parameter tensor, in matrix mode `mode`.  The oracle side (minutes of fp64 CPU time) is a committed fixture written by
+    tests/golden/make_fullsize_golden.py (case qm9_l2_bench: same seeds, same generators); the weights are the oracle's own
+    initialisation under torch.manual_seed(0), rebuilt here (construction only) and loaded into the HIP model."""
     from equiformer_amd import nets, ops
+    import fullsize
     dev = _dev()
+    meta, outs, gref = fullsize.load("qm9_l2_bench")
     torch.manual_seed(0)
-    ref = onets.graph_attention_transformer_nonlinear_l2("5x0e", 5.0).double().eval()
+    ref = onets.graph_attention_transformer_nonlinear_l2("5x0e", 5.0)  # (weights only: the oracle is not evaluated here)
     mod = nets.model_entrypoint("graph_attention_transformer_nonlinear_l2")(irreps_in="5x0e", radius=5.0)
     mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
     mod = mod.to(dev).eval()
     d = _bench_batch()
-    yr = ref(None, d["pos"].double(), d["batch"], d["z"])
-    gr = torch.autograd.grad((yr.squeeze() - d["y"].double()).abs().mean(), list(ref.parameters()), allow_unused=True)
+    assert int(meta["molecules"]) == 128 and int(meta["seed"]) == 11
+    yr = outs["energy"]
     with ops.matrix_mode(mode):
         y = mod(None, d["pos"].to(dev), d["batch"].to(dev), d["z"].to(dev))
         gg = torch.autograd.grad((y.squeeze() - d["y"].to(dev)).abs().mean(), list(mod.parameters()), allow_unused=True)
     err = _rel(y.cpu(), yr)
-    worst = []
-    for (n, _), a, r in zip(ref.named_parameters(), gg, gr):
-        assert (a is None) == (r is None), n
-        if r is None or r.abs().max() == 0:
-            continue
-        worst.append((_rel(a.cpu(), r), n))
-    worst.sort(reverse=True)
+    named = {n: g for (n, _), g in zip(mod.named_parameters(), gg)}
+    assert [n for n, _ in mod.named_parameters()] == [n for n, _ in ref.named_parameters()]
+    worst = fullsize.compare_summary(named, gref, float("inf"))
     print("128 molecules, matrix mode %s: energy rel err vs fp64 oracle %.3e; worst parameter-gradient rel errs: %s"
           % (mode, err, ["%s %.2e" % (n, e) for e, n in worst[:5]]))
     return err, worst

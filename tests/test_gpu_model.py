@@ -280,43 +280,90 @@ def test_md17_differentiable_forces_in_eval_mode():
             assert _rel(a, b) < 1e-5, n
 
 
+def _md17_fixture_case(case, name, grads):
+    """A full-size MD17 case of tests/golden/make_fullsize_golden.py: the oracle's E, F (and force-loss gradients of every
+    parameter: its double backward) come from the committed fixture, weights and inputs are rebuilt from the same seeds."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fullsize
+    import make_fullsize_golden as mk
+    from equiformer_amd import nets
+    from equiformer_amd.synthetic import md17_aspirin_batch
+    dev = _dev()
+    meta, outs, gref = fullsize.load(case)
+    frames = int(meta["frames"])
+    torch.manual_seed(0)
+    ref = onets.model_entrypoint(name)("64x0e", 5.0, num_basis=32)  # (weights only)
+    mod = nets.model_entrypoint(name)(irreps_in="64x0e", radius=5.0, num_basis=32)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
+    mod = mod.to(dev).train()
+    d = md17_aspirin_batch(frames, seed=int(meta["seed"]))
+    E, F = mod(node_atom=d["z"].to(dev), pos=d["pos"].to(dev), batch=d["batch"].to(dev))
+    eE, eF = _rel(E, outs["energy"]), _rel(F, outs["forces"])
+    worst = []
+    if grads:
+        assert F.requires_grad
+        a, B = mk.md17_probe(frames, int(meta["probe_seed"]))
+        gg = torch.autograd.grad((a.float().to(dev) * E).sum() + (B.float().to(dev) * F).sum(), list(mod.parameters()),
+                                 allow_unused=True)
+        for x in gg:
+            assert x is None or torch.isfinite(x).all()
+        worst = fullsize.compare_summary({n: g for (n, _), g in zip(mod.named_parameters(), gg)}, gref, float("inf"))
+    print("%s (%d frames): E rel %.2e, F rel %.2e, mean|dF| %.2e, worst force-loss gradient %s over %d tensors"
+          % (case, frames, eE, eF, (F.detach().double().cpu() - outs["forces"]).abs().mean().item(),
+             ("%s %.2e" % (worst[0][1], worst[0][0])) if worst else "-", len(worst)))
+    assert eE < 1e-4 and eF < 1e-4
+    return mod, worst
+
+
 def test_md17_l3_full_size_force_loss_gradients():
     """BASELINE config #4 at full size: the registered L_max = 3 MD17 model (graph_attention_transformer_nonlinear_exp_l3_md17,
     5 500 865 parameters; reference: nets/graph_attention_transformer_md17.py:426-442 with the create_graph forces of :318-325)
     on one aspirin frame: energy, forces and the gradient of a force loss w.r.t. EVERY parameter -- the second-order path
-    through the degree-3 kernels -- against the fp64 oracle's double backward (~1 minute of CPU)."""
-    from equiformer_amd import nets
-    from equiformer_amd.synthetic import md17_aspirin_batch
-    dev = _dev()
-    torch.manual_seed(0)
-    ref = onets.graph_attention_transformer_nonlinear_exp_l3_md17("64x0e", 5.0, num_basis=32).double().train()
-    mod = nets.model_entrypoint("graph_attention_transformer_nonlinear_exp_l3_md17")(irreps_in="64x0e", radius=5.0, num_basis=32)
-    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
-    mod = mod.to(dev).train()
+    through the degree-3 kernels -- against the fp64 oracle's double backward (fixture md17_l3_second_order)."""
+    mod, worst = _md17_fixture_case("md17_l3_second_order", "graph_attention_transformer_nonlinear_exp_l3_md17", True)
     assert sum(p.numel() for p in mod.parameters()) == 5500865
-    d = md17_aspirin_batch(1, seed=4)
-    g = torch.Generator().manual_seed(1)
-    a = torch.randn(1, 1, generator=g, dtype=torch.float64)
-    B = torch.randn(21, 3, generator=g, dtype=torch.float64)
-    Er, Fr = ref(d["z"], d["pos"].double(), d["batch"])
-    gr = torch.autograd.grad((a * Er).sum() + (B * Fr).sum(), list(ref.parameters()), allow_unused=True)
-    E, F = mod(node_atom=d["z"].to(dev), pos=d["pos"].to(dev), batch=d["batch"].to(dev))
-    assert F.requires_grad
-    gg = torch.autograd.grad((a.float().to(dev) * E).sum() + (B.float().to(dev) * F).sum(), list(mod.parameters()),
-                             allow_unused=True)
-    eE, eF = _rel(E, Er), _rel(F, Fr)
-    worst, n = ("", 0.0), 0
-    for (name, _), x, r in zip(ref.named_parameters(), gg, gr):
-        if r is None or r.abs().max() == 0:
-            continue
-        assert x is not None and torch.isfinite(x).all(), name
-        n += 1
-        e = _rel(x, r)
-        if e > worst[1]:
-            worst = (name, e)
-    print("L3 full size, 1 frame: E rel %.2e, F rel %.2e, worst second-order gradient %s %.2e over %d tensors" % (eE, eF, *worst, n))
-    assert eE < 1e-4 and eF < 1e-4
-    assert n > 100 and worst[1] < 1e-4, worst
+    assert len(worst) > 100 and worst[0][0] < 1e-4, worst[:5]
+
+
+def test_md17_l2_bench_batch_energy_forces_and_force_loss_gradients():
+    """BASELINE config #3 AT THE BENCH BATCH (8 aspirin frames, the reference script's batch): E, F and the force-loss
+    gradient of every parameter against the fp64 oracle (fixture md17_l2_bench8; round 4 compared 3 frames only)."""
+    _, worst = _md17_fixture_case("md17_l2_bench8", "graph_attention_transformer_nonlinear_exp_l2_md17", True)
+    assert len(worst) > 100 and worst[0][0] < 1e-4, worst[:5]
+
+
+def test_md17_l3_bench_batch_energy_and_forces():
+    """BASELINE config #4 at the bench batch (5 frames): E and F against the fp64 oracle (fixture md17_l3_bench5)."""
+    _md17_fixture_case("md17_l3_bench5", "graph_attention_transformer_nonlinear_exp_l3_md17", False)
+
+
+def test_oc20_bench_batch_energies():
+    """BASELINE config #5 at the bench batch: 16 structures x 78 atoms, periodic graph built on the device from data.cell
+    (otf_graph, use_pbc), energies of all 16 structures against the fp64 oracle on the oracle's own periodic edge list
+    (fixture oc20_bench16; round 4 compared 2 x 40 atoms only)."""
+    import os
+    import sys
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fullsize
+    import make_fullsize_golden as mk
+    from equiformer_amd import nets
+    dev = _dev()
+    meta, outs, _ = fullsize.load("oc20_bench16")
+    torch.manual_seed(0)
+    ref = onets.oc20_l1_256_nonlinear()  # (weights only)
+    mod = nets.model_entrypoint("oc20_l1_256_nonlinear")()
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
+    mod = mod.to(dev).eval()
+    d = mk.oc20_bench_batch()
+    data = SimpleNamespace(**{k: v.to(dev) for k, v in d.items()})
+    with torch.no_grad():
+        y = mod(data)
+    err = _rel(y, outs["energy"])
+    print("oc20 bench batch (16 x 78 atoms, %d periodic edges in the oracle's list): energy rel %.3e" % (int(meta["edges"]), err))
+    assert y.shape[0] == 16 and err < 1e-4
 
 
 @pytest.mark.parametrize("basis,nonlinear", [("bessel", True), ("gaussian", False)])

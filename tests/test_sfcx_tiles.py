@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = open(os.path.join(ROOT, "equiformer_amd", "csrc", "sfcx_common.h")).read()  # shared by sfcx.hip and sfcx_bwd2.hip
+SRC = open(os.path.join(ROOT, "equiformer_amd", "csrc", "sfcx_common.h")).read()
 XT_LD = int(re.search(r"constexpr int XT_LD = (\d+);", SRC).group(1))
 LANES = np.arange(64)
 R, HI = LANES & 31, LANES >> 5

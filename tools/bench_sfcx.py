@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Micro-benchmark of the split-precision SeparableFCTP kernels (csrc/sfcx.hip, sfcx_bwd2.hip) at the bench shapes:
-   python tools/bench_sfcx.py [E] [modes, e.g. 0,1]
-us / call of forward, data gradient (multi-wave kernel and, through the development switch, the one-wave kernel; their
-results are compared), weight gradient."""
+"""Micro-benchmark of the split-precision SeparableFCTP kernels (csrc/sfcx.hip) at the bench shapes:
+   python tools/bench_sfcx.py [E] [modes, e.g. 0,1] [--l3] [--dm]
+us / call of forward, data gradient, weight gradient.  --l3: the L_max = 3 MD17 shapes as well; --dm: the force-evaluation
+variant (d_coupling) of the data gradient.  A/B of kernel variants: EQF_LIB_VARIANT=<name> (equiformer_amd/build.py --variant)."""
 import ctypes
 import os
 import sys
@@ -63,25 +63,15 @@ def run(name, irr, sh_irr, out_irr, n2, use_w, want_dM=False):
         packed = ops._sfc_pack(weight, weight2, spec, mode)
         PK = ctypes.c_void_p(packed.data_ptr())
 
-        def bwd(version):
-            L.eqf_sfcx_dev_set(0, version)
-            dx = torch.full_like(x, float("nan"))
-            dw = torch.full_like(w, float("nan")) if use_w else None
-            dM = torch.zeros_like(M) if want_dM else None
-            fn = lambda: call("eqf_sfcx_bwd_data", P(x), P(M), P(w), table.c_ref, PK, P(d1), lay.c_ref, P(d2), n2,  # noqa: E731
-                              P(dx), P(dw), P(dM), E, mode, st())
-            fn()
-            torch.cuda.synchronize()
-            res = (dx.clone(), dw.clone() if use_w else None, dM.clone() if want_dM else None)
-            us = timeit(fn)
-            L.eqf_sfcx_dev_set(0, 0)
-            return us, res
-        us1, r1 = bwd(1)
-        us2, r2 = bwd(2)
-        errs = ["%.1e" % rel(a, b) if a is not None else "-" for a, b in zip(r2, r1)]
-        fin = all(torch.isfinite(a).all().item() for a in r2 if a is not None)
-        print("%-10s mode %d%s bwd_data  one-wave %7.1f us   multi-wave %7.1f us  (%5.1f TFLOP/s)   multi vs one-wave: dx %s dw %s dM %s  finite %s"
-              % (name, mode, " dM" if want_dM else "", us1, us2, flops / us2 / 1e6, *errs, fin), flush=True)
+        dx = torch.full_like(x, float("nan"))
+        dw = torch.full_like(w, float("nan")) if use_w else None
+        dM = torch.zeros_like(M) if want_dM else None
+        bw = lambda: call("eqf_sfcx_bwd_data", P(x), P(M), P(w), table.c_ref, PK, P(d1), lay.c_ref, P(d2), n2,  # noqa: E731
+                          P(dx), P(dw), P(dM), E, mode, st())
+        us = timeit(bw)
+        fin = all(torch.isfinite(a).all().item() for a in (dx, dw) if a is not None)
+        print("%-10s mode %d%s bwd_data   %7.1f us  (%5.1f TFLOP/s)  finite %s"
+              % (name, mode, " dM" if want_dM else "", us, flops / us / 1e6, fin), flush=True)
         if want_dM:
             continue
         fx = lambda: call("eqf_sfcx_fwd", P(x), P(M), P(w), table.c_ref, PK, None, None, P(o1), lay.c_ref, P(o2), n2, E,  # noqa: E731
@@ -97,3 +87,8 @@ run("sep_act", "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "224x0e+64x1e+32x2e", 128
 run("sep_value", "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "128x0e+64x1e+32x2e", 0, False)
 if "--dm" in sys.argv:
     run("sep_act", "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "224x0e+64x1e+32x2e", 128, True, want_dM=True)
+if "--l3" in sys.argv:  # graph_attention_transformer_nonlinear_exp_l3_md17: 5 aspirin frames = 1 742 edges in the bench
+    I3, S3 = "128x0e+64x1e+64x2e+32x3e", "1x0e+1x1e+1x2e+1x3e"
+    run("l3_act", I3, S3, "288x0e+64x1e+64x2e+32x3e", 128, True)
+    run("l3_act", I3, S3, "288x0e+64x1e+64x2e+32x3e", 128, True, want_dM=True)
+    run("l3_value", I3, S3, I3, 0, False, want_dM=True)

@@ -25,7 +25,20 @@ from equiformer_amd.build import source_hash  # noqa: E402
 d = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "pmc_dominant.json")
 PROF = {"sfc_fwd_kernel": "sfc_fwd", "sfc_bwd_kernel": "sfc_bwd_data", "sfc_wgrad_kernel": "sfc_wgrad",
-        "sfcx_fwd_kernel": "sfcx_fwd", "sfcx_bwd_kernel": "sfcx_bwd_data", "sfcx_wgrad_kernel": "sfcx_wgrad"}
+        "sfcx_fwd_kernel": "sfcx_fwd", "sfcx_bwd_kernel": "sfcx_bwd_data", "sfcx_wgrad_kernel": "sfcx_wgrad",
+        # the two kernels BASELINE.json's north_star names: per-destination softmax + scatter, widest radial-MLP layer
+        "attn_fwd_half_kernel": "attn_fwd", "attn_fwd_kernel": "attn_fwd", "gemmx_rows_wide_kernel": "gemmx_rows_wide"}
+# average durations of the same kernels from the kernel trace of the SAME build (tools/gpu_profile.sh writes kernel_stats.csv
+# next to the PMC directories): lets bench.py state MFMA utilisation of the radial kernel from its counter alone
+avg_us = {}
+ks = os.path.join(d, "kernel_stats.csv")
+if os.path.exists(ks):
+    for r in csv.DictReader(open(ks)):
+        for needle, name in PROF.items():
+            if needle in r["kernel"]:
+                a = avg_us.setdefault(name, [0.0, 0])
+                a[0] += float(r["total_us"])
+                a[1] += int(r["calls"])
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(d + "/pmc_*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
@@ -45,6 +58,10 @@ for name, c in vals.items():
     m = c.get("SQ_INSTS_MFMA", [])
     if m:
         res[name]["mfma_insts_per_launch"] = sum(m) / len(m)
+    if name in avg_us and avg_us[name][1]:
+        res[name]["avg_us_kernel_trace"] = avg_us[name][0] / avg_us[name][1]
+        if m:  # 32 cycles per v_mfma_f32_32x32x16_bf16, 1 024 SIMDs at 2.4 GHz
+            res[name]["mfma_busy"] = res[name]["mfma_insts_per_launch"] * 32.0 / 1024 / 2.4e9 / (res[name]["avg_us_kernel_trace"] * 1e-6)
     print("%-14s %.1f MB / launch (fetch %.1f + write %.1f, %d launches)" % (name, (fetch + write) / 1e6, fetch / 1e6,
                                                                           write / 1e6, len(f)))
 json.dump(res, open(out, "w"), indent=1)
