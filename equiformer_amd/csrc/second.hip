@@ -117,6 +117,9 @@ __global__ __launch_bounds__(256) void lnsilu_bwd2_kernel(const float* __restric
                                                           const float* __restrict__ c, float* __restrict__ g_x,
                                                           float* __restrict__ g_gamma, float* __restrict__ g_beta,
                                                           float* __restrict__ g_dy, int rows, int C, float eps) {
+  // blockIdx.y = group: rows are [groups][C] wide, every group has its own gamma / beta [C] (the radial bank, round 5)
+  const int grp = blockIdx.y, ld = C * gridDim.y;
+  gamma += grp * C, beta += grp * C, g_gamma += grp * C, g_beta += grp * C;
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * WPB + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * WPB;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void lnsilu_bwd2_kernel(const float* __restric
   const float invC = 1.f / (float)C;
   float acc_g = 0.f, acc_b = 0.f;
   for (int row = wave_global; row < rows; row += nwaves) {
-    const long o = (long)row * C + lane;
+    const long o = (long)row * ld + grp * C + lane;
     const float v = act ? x[o] : 0.f;
     const float mean = wave_sum(v) * invC;
     const float dv = act ? v - mean : 0.f;
@@ -606,17 +609,24 @@ int eqf_gate_bwd2(const float* in, const float* d_out, const float* c, float* g_
   return 0;
 }
 
-int eqf_lnsilu_bwd2(const float* x, const float* gamma, const float* beta, const float* dy, const float* c, float* g_x,
-                    float* g_gamma, float* g_beta, float* g_dy, int rows, int C, float eps, void* stream) {
-  if (!x || !gamma || !beta || !dy || !c || !g_x || !g_gamma || !g_beta || !g_dy || C < 1) return EQF_E_BADARG;
+int eqf_lnsilu_group_bwd2(const float* x, const float* gamma, const float* beta, const float* dy, const float* c,
+                          float* g_x, float* g_gamma, float* g_beta, float* g_dy, int rows, int C, int groups, float eps,
+                          void* stream) {
+  if (!x || !gamma || !beta || !dy || !c || !g_x || !g_gamma || !g_beta || !g_dy || C < 1 || groups < 1 || groups > 65535)
+    return EQF_E_BADARG;
   if (C > 64) return EQF_E_UNSUPPORTED;
   if (rows <= 0) return 0;
   int blocks = eqf_cdiv(rows, WPB * 2);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(lnsilu_bwd2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy, c, g_x,
+  hipLaunchKernelGGL(lnsilu_bwd2_kernel, dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy, c, g_x,
                      g_gamma, g_beta, g_dy, rows, C, eps);
   EQF_CHECK_LAUNCH();
   return 0;
+}
+
+int eqf_lnsilu_bwd2(const float* x, const float* gamma, const float* beta, const float* dy, const float* c, float* g_x,
+                    float* g_gamma, float* g_beta, float* g_dy, int rows, int C, float eps, void* stream) {
+  return eqf_lnsilu_group_bwd2(x, gamma, beta, dy, c, g_x, g_gamma, g_beta, g_dy, rows, C, 1, eps, stream);
 }
 
 int eqf_layernorm_bwd2(const float* x, const float* weight, const float* dy, const float* c, float* g_x, float* g_weight,

@@ -293,6 +293,7 @@ struct XBwdArgs {
   float *dx, *dw, *dM;
   const __bf16* packed;
   int ms;
+  int only_d1;  // development switch: 0, or the only input degree (2 l + 1) whose items run
   XGate gate;
   SfcOrder ord;  // nx = edge tiles, ny = groups of this launch
   struct Deg {

@@ -130,6 +130,7 @@ SIGNATURES = {
     "eqf_silu_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, _long, _f, c_fp],
     "eqf_gate_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _f, c_fp],
     "eqf_lnsilu_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _f, c_fp],
+    "eqf_lnsilu_group_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
     "eqf_layernorm_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, _P_IRR, _f, c_fp],
     "eqf_alpha_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
     "eqf_attn_aggregate_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64,

@@ -150,9 +150,9 @@ class _Trunk(nn.Module):
     def _trunk_features(self, node_embedding, pos, graph, offsets=None, extra=None):
         _, edge_length, edge_sh = ops.edge_geometry(pos, offsets, graph, self.lmax_sh)
         edge_scalars = self.rbf(edge_length)
-        # the radial MLPs of all blocks side by side (RadialBank); it has no second-order backward, so it steps aside when
-        # forces are being taken with create_graph (MD17 training)
-        bank = self._radial_bank() if not getattr(self, "_second_order_pass", False) else None
+        # the radial MLPs of all blocks side by side (RadialBank): first- and second-order (forces taken with create_graph:
+        # MD17 / DeNS training) alike since round 5
+        bank = self._radial_bank()
         ectx = EdgeContext(graph, edge_sh, edge_scalars, radial_bank=bank)
         # residual stream kept as a lazy pair (a, b) = a + b: each add is folded into the layer norm that consumes it
         a, b = node_embedding, self.edge_deg_embed(node_embedding, ectx)
@@ -186,7 +186,12 @@ class GraphAttentionTransformer(_Trunk):
         if graph is None:
             graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=1000)
         # atomic number -> type index  [ref: nets/graph_attention_transformer.py:872]
-        node_atom = node_atom.new_tensor([-1, 0, -1, -1, -1, -1, 1, 2, 3, 4])[node_atom]
+        # (the table lives on the device, built once per device: no host-to-device copy per step, legal under graph capture)
+        table = self.__dict__.get("_z_table")
+        if table is None or table.device != node_atom.device or table.dtype != node_atom.dtype:
+            table = node_atom.new_tensor([-1, 0, -1, -1, -1, -1, 1, 2, 3, 4])
+            self.__dict__["_z_table"] = table  # plain attribute: not a buffer, not in the state_dict
+        node_atom = table[node_atom]
         atom_embedding, _, _ = self.atom_embed(node_atom)
         outputs = self._trunk_forward(atom_embedding, pos.to(torch.float32).contiguous(), graph)
         if self.scale is not None:

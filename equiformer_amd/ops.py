@@ -158,6 +158,9 @@ except AttributeError:  # pragma: no cover
 
 
 
+_capturing = getattr(torch._C, "_cuda_isCurrentStreamCapturing", lambda: False)
+
+
 class _ZeroArena:
     """Zero-initialised fp32 accumulators (the targets of atomically accumulated weight / bias gradients) are carved
     out of slabs that are filled ONCE, instead of one fill launch per tensor (209 fill launches per QM9 step before).
@@ -170,7 +173,9 @@ class _ZeroArena:
         self.slabs = {}
 
     def take(self, numel, device):
-        if numel == 0 or numel > self.MAX_REQ or device.type != "cuda":
+        if numel == 0 or numel > self.MAX_REQ or device.type != "cuda" or _capturing():
+            # (under HIP-graph capture every accumulator gets its own fill NODE: a replay must zero it again, and a slab that
+            # was filled before the capture would be accumulated into once per replay)
             return torch.zeros(numel, device=device, dtype=torch.float32)
         idx = device.index if device.index is not None else torch.cuda.current_device()
         key = (idx, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
@@ -998,10 +1003,7 @@ class _LnSilu(Function):
         x, gamma, beta = ctx.saved_tensors
         G = ctx.groups
         if torch.is_grad_enabled():  # create_graph
-            if G != 1:
-                raise NotImplementedError("grouped LayerNorm+SiLU has no second-order backward (the radial bank is "
-                                          "bypassed when forces are taken with create_graph)")
-            dx, dg, db = _LnSiluBwd.apply(x, gamma, beta, dy, ctx.eps)
+            dx, dg, db = _LnSiluBwd.apply(x, gamma, beta, dy, ctx.eps, G)
             return dx, _guard_opt(dg, dy, "LayerNorm weight gradient"), _guard_opt(db, dy, "LayerNorm bias gradient"), \
                 None, None
         dy = _c(dy)
@@ -1015,15 +1017,15 @@ class _LnSilu(Function):
 
 class _LnSiluBwd(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, dy, eps):
+    def forward(ctx, x, gamma, beta, dy, eps, groups=1):
         dy = _c(dy)
         _chk(dy)
         dx = torch.empty_like(x)
         dg, db = _zeros2(gamma.numel(), beta.numel(), x.device)
-        call("eqf_lnsilu_bwd", _p(x), _p(gamma), _p(beta), _p(dy), _p(dx), _p(dg), _p(db), x.shape[0], x.shape[1], eps,
-             _stream())
+        call("eqf_lnsilu_group_bwd", _p(x), _p(gamma), _p(beta), _p(dy), _p(dx), _p(dg), _p(db), x.shape[0],
+             x.shape[1] // groups, groups, eps, _stream())
         ctx.save_for_backward(x, gamma, beta, dy)
-        ctx.eps = eps
+        ctx.eps, ctx.groups = eps, groups
         if not _want_param_grads():
             return dx, None, None
         ctx.mark_non_differentiable(dg, db)
@@ -1037,9 +1039,10 @@ class _LnSiluBwd(Function):
         _chk(c)
         g_x, g_dy = torch.empty_like(x), torch.empty_like(x)
         g_g, g_b = _zeros2(gamma.numel(), beta.numel(), x.device)
-        call("eqf_lnsilu_bwd2", _p(x), _p(gamma), _p(beta), _p(dy), _p(c), _p(g_x), _p(g_g), _p(g_b), _p(g_dy),
-             x.shape[0], x.shape[1], ctx.eps, _stream())
-        return g_x, g_g, g_b, g_dy, None
+        G = ctx.groups
+        call("eqf_lnsilu_group_bwd2", _p(x), _p(gamma), _p(beta), _p(dy), _p(c), _p(g_x), _p(g_g), _p(g_b), _p(g_dy),
+             x.shape[0], x.shape[1] // G, G, ctx.eps, _stream())
+        return g_x, g_g, g_b, g_dy, None, None
 
 
 def ln_silu(x, gamma, beta, eps=1e-5, groups=1):
@@ -1048,11 +1051,131 @@ def ln_silu(x, gamma, beta, eps=1e-5, groups=1):
     return _LnSilu.apply(x, gamma, beta, eps, int(groups))
 
 
+def _glin_views(dys, wide, Ns, rows_n, dev):
+    """(per-group dy tensors, their column offsets, their row stride or None) of a grouped linear's output gradient"""
+    G = len(Ns)
+    if wide:
+        dy = _c(dys[0])
+        _chk(dy)
+        return [dy] * G, [sum(Ns[:g]) for g in range(G)], sum(Ns)
+    dyt = [(_c(d) if d is not None else _zeros((rows_n, Ns[g]), dev)) for g, d in enumerate(dys)]
+    _chk(*dyt)
+    return dyt, [0] * G, None
+
+
+def _glin_fwd(x, K, wide, Ws, bs):
+    """y_g = x[:, g K:(g+1) K] W_g^T (+ b_g) for all g in one launch; one [rows, sum N] tensor if `wide`, else a tuple"""
+    G = len(Ws)
+    rows_n, ldx = x.shape
+    Ns = [int(W.shape[0]) for W in Ws]
+    if wide:
+        out = torch.empty((rows_n, sum(Ns)), device=x.device, dtype=torch.float32)
+        outs, ldo, offs = [out] * G, sum(Ns), [sum(Ns[:g]) for g in range(G)]
+    else:
+        outs = [torch.empty((rows_n, n), device=x.device, dtype=torch.float32) for n in Ns]
+        ldo, offs = None, [0] * G
+    descs = [_desc(1, (x, g * K), rows(1, ldx, 0), (Ws[g], 0), K, (outs[g], offs[g]),
+                   rows(1, ldo if wide else Ns[g], 0), bs[g], rows_n, Ns[g], K) for g in range(G)]
+    _gemm_group(descs, _stream())
+    return out if wide else tuple(outs)
+
+
+def _glin_dgrad(dyt, offs, ldd, Ws, K, rows_n):
+    """dx[:, g K:(g+1) K] = dy_g W_g"""
+    G = len(Ws)
+    Ns = [int(W.shape[0]) for W in Ws]
+    dx = torch.empty((rows_n, G * K), device=dyt[0].device, dtype=torch.float32)
+    _gemm_group([_desc(0, (dyt[g], offs[g]), rows(1, ldd if ldd is not None else Ns[g], 0), (Ws[g], 0), K, (dx, g * K),
+                       rows(1, G * K, 0), None, rows_n, K, Ns[g]) for g in range(G)], _stream())
+    return dx
+
+
+def _glin_wgrad(dyt, offs, ldd, x, K, Ns, has_b):
+    """dW_g[N_g, K] = dy_g^T x_g, db_g = column sums of dy_g (same launch); one zero-filled flat buffer behind all of them"""
+    G = len(Ns)
+    rows_n, ldx = x.shape
+    sizes = [n * K for n in Ns] + [n if hb else 0 for n, hb in zip(Ns, has_b)]
+    flat = _zeros(sum(sizes), x.device)
+    o, dWs, dbs = 0, [], []
+    for g in range(G):
+        dWs.append(flat[o:o + Ns[g] * K].view(Ns[g], K))
+        o += Ns[g] * K
+    for g in range(G):
+        dbs.append(flat[o:o + Ns[g]] if has_b[g] else None)
+        o += Ns[g] if has_b[g] else 0
+    _gemm_group([_desc(3, (dyt[g], offs[g]), rows(1, ldd if ldd is not None else Ns[g], 0), (x, g * K), K, (dWs[g], 0),
+                       rows(1, ldx, 0), dbs[g], Ns[g], K, rows_n) for g in range(G)], _stream())
+    return dWs, dbs
+
+
+class _GroupedDgrad(Function):
+    """dx = [dy_g W_g]_g as a differentiable op (create_graph only).  args = dys (one wide tensor or G tensors) + the G weights."""
+
+    @staticmethod
+    def forward(ctx, K, wide, G, *args):
+        ndy = 1 if wide else G
+        dys, Ws = args[:ndy], [_c(W) for W in args[ndy:]]
+        Ns = [int(W.shape[0]) for W in Ws]
+        rows_n = next(d.shape[0] for d in dys if d is not None)
+        dyt, offs, ldd = _glin_views(dys, wide, Ns, rows_n, Ws[0].device)
+        ctx.save_for_backward(*dyt[:ndy], *Ws)
+        ctx.meta = (K, wide, G, Ns, rows_n)
+        return _glin_dgrad(dyt, offs, ldd, Ws, K, rows_n)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c):
+        K, wide, G, Ns, rows_n = ctx.meta
+        ndy = 1 if wide else G
+        saved = ctx.saved_tensors
+        dys, Ws = saved[:ndy], list(saved[ndy:])
+        c = _c(c)
+        _chk(c)
+        g_dys = _glin_fwd(c, K, wide, Ws, [None] * G)  # d <c, dx> / d dy_g = c_g W_g^T
+        g_dys = (g_dys,) if wide else tuple(g_dys)
+        dyt, offs, ldd = _glin_views(dys, wide, Ns, rows_n, c.device)
+        g_Ws, _ = _glin_wgrad(dyt, offs, ldd, c, K, Ns, [False] * G)  # d <c, dx> / d W_g = dy_g^T c_g
+        return (None, None, None) + g_dys + tuple(g_Ws)
+
+
+class _GroupedWgrad(Function):
+    """(dW_0..dW_{G-1}, db_g of the groups that have a bias) as a differentiable op (create_graph only).  args = x + dys."""
+
+    @staticmethod
+    def forward(ctx, K, wide, Ns, has_b, x, *dys):
+        x = _c(x)
+        _chk(x)
+        dyt, offs, ldd = _glin_views(dys, wide, list(Ns), x.shape[0], x.device)
+        ndy = 1 if wide else len(Ns)
+        ctx.save_for_backward(x, *dyt[:ndy])
+        ctx.meta = (K, wide, list(Ns), list(has_b))
+        dWs, dbs = _glin_wgrad(dyt, offs, ldd, x, K, list(Ns), list(has_b))
+        return tuple(dWs) + tuple(b for b in dbs if b is not None)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *cs):
+        K, wide, Ns, has_b = ctx.meta
+        G = len(Ns)
+        x, *dys = ctx.saved_tensors
+        dev = x.device
+        cWs = [(_c(cs[g]) if cs[g] is not None else _zeros((Ns[g], K), dev)) for g in range(G)]
+        it = iter(cs[G:])
+        cbs = [(next(it) if hb else None) for hb in has_b]
+        cbs = [(_c(b) if b is not None else None) for b in cbs]
+        dyt, offs, ldd = _glin_views(dys, wide, Ns, x.shape[0], dev)
+        g_x = _glin_dgrad(dyt, offs, ldd, cWs, K, x.shape[0]) if ctx.needs_input_grad[4] else None  # dy_g cW_g
+        g_dys = _glin_fwd(x, K, wide, cWs, cbs)  # x_g cW_g^T + cb_g
+        g_dys = (g_dys,) if wide else tuple(g_dys)
+        return (None, None, None, None, g_x) + g_dys
+
+
 class _GroupedLinear(Function):
     """G independent nn.Linear layers on the column blocks of one wide input: y_g = x[:, g K:(g+1) K] W_g^T + b_g, all G
     GEMMs in ONE launch (eqf_gemm_group), forward and both gradients.  `wide`: the outputs form one [rows, sum N_g]
     tensor (returned as such), otherwise G separate [rows, N_g] tensors.  params = (W_0..W_{G-1}, b_0..b_{G-1}).
-    First-order only (used by the radial bank, which steps aside under create_graph)."""
+    Under create_graph the backward is made of differentiable grouped pieces (round 5: the radial bank no longer steps aside
+    when forces are taken, MD17 / DeNS training)."""
 
     @staticmethod
     def forward(ctx, x, K, wide, *params):
@@ -1063,54 +1186,33 @@ class _GroupedLinear(Function):
         rows_n, ldx = x.shape
         Ns = [int(W.shape[0]) for W in Ws]
         assert ldx == G * K and all(W.shape[1] == K and W.is_contiguous() for W in Ws)
-        if wide:
-            out = torch.empty((rows_n, sum(Ns)), device=x.device, dtype=torch.float32)
-            outs, ldo, offs = [out] * G, sum(Ns), [sum(Ns[:g]) for g in range(G)]
-        else:
-            outs = [torch.empty((rows_n, n), device=x.device, dtype=torch.float32) for n in Ns]
-            ldo, offs = None, [0] * G
-        descs = [_desc(1, (x, g * K), rows(1, ldx, 0), (Ws[g], 0), K, (outs[g], offs[g]),
-                       rows(1, ldo if wide else Ns[g], 0), bs[g], rows_n, Ns[g], K) for g in range(G)]
-        _gemm_group(descs, _stream())
+        out = _glin_fwd(x, K, wide, list(Ws), list(bs))
         ctx.save_for_backward(x, *Ws)
         ctx.meta = (G, K, wide, Ns, [b is not None for b in bs])
-        return out if wide else tuple(outs)
+        return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, *dys):
         x, *Ws = ctx.saved_tensors
         G, K, wide, Ns, has_b = ctx.meta
         rows_n, ldx = x.shape
         dev = x.device
-        if wide:
-            dy = _c(dys[0])
-            _chk(dy)
-            ldd, offs, dyt = sum(Ns), [sum(Ns[:g]) for g in range(G)], [dy] * G
-        else:
-            dyt = [(_c(d) if d is not None else _zeros((rows_n, Ns[g]), dev)) for g, d in enumerate(dys)]
-            _chk(*dyt)
-            ldd, offs = None, [0] * G
-        st = _stream()
+        if torch.is_grad_enabled():  # create_graph: every piece is itself differentiable
+            dlist = [dys[0]] if wide else [(d if d is not None else _zeros((rows_n, Ns[g]), dev)) for g, d in enumerate(dys)]
+            dx = _GroupedDgrad.apply(K, wide, G, *dlist, *Ws) if ctx.needs_input_grad[0] else None
+            if not _want_param_grads():
+                return (dx, None, None) + (None,) * (2 * G)
+            outs = _GroupedWgrad.apply(K, wide, tuple(Ns), tuple(has_b), x, *dlist)
+            it = iter(outs[G:])
+            return (dx, None, None) + tuple(outs[:G]) + tuple((next(it) if hb else None) for hb in has_b)
+        dyt, offs, ldd = _glin_views(dys, wide, Ns, rows_n, dev)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            _gemm_group([_desc(0, (dyt[g], offs[g]), rows(1, ldd if wide else Ns[g], 0), (Ws[g], 0), K, (dx, g * K),
-                               rows(1, ldx, 0), None, rows_n, K, Ns[g]) for g in range(G)], st)
+            dx = _glin_dgrad(dyt, offs, ldd, list(Ws), K, rows_n)
         if not _want_param_grads():
             return (dx, None, None) + (None,) * (2 * G)
-        sizes = [n * K for n in Ns] + [n if hb else 0 for n, hb in zip(Ns, has_b)]
-        flat = _zeros(sum(sizes), dev)
-        o, dWs, dbs = 0, [], []
-        for g in range(G):
-            dWs.append(flat[o:o + Ns[g] * K].view(Ns[g], K))
-            o += Ns[g] * K
-        for g in range(G):
-            dbs.append(flat[o:o + Ns[g]] if has_b[g] else None)
-            o += Ns[g] if has_b[g] else 0
         # kind 3: dW_g[N_g, K] += dy_g^T x_g, db_g += column sums of dy_g (same launch)
-        _gemm_group([_desc(3, (dyt[g], offs[g]), rows(1, ldd if wide else Ns[g], 0), (x, g * K), K, (dWs[g], 0),
-                           rows(1, ldx, 0), dbs[g], Ns[g], K, rows_n) for g in range(G)], st)
+        dWs, dbs = _glin_wgrad(dyt, offs, ldd, x, K, Ns, has_b)
         return (dx, None, None) + tuple(dWs) + tuple(dbs)
 
 

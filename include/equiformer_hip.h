@@ -481,6 +481,12 @@ int eqf_gate_bwd2(const float* in, const float* d_out, const float* c, float* g_
 /* g_gamma[C], g_beta[C] ACCUMULATED */
 int eqf_lnsilu_bwd2(const float* x, const float* gamma, const float* beta, const float* dy, const float* c,
                     float* g_x, float* g_gamma, float* g_beta, float* g_dy, int rows, int C, float eps, void* stream);
+/* the same on [rows][groups][C] rows with per-group gamma / beta (g_gamma / g_beta [groups][C], ACCUMULATED): the second-order
+ * term of the radial bank -- all RadialProfile MLPs of a model side by side -- when forces are taken with create_graph
+ * [ref: nets/radial_func.py:13-36 under nets/graph_attention_transformer_md17.py:318-325] */
+int eqf_lnsilu_group_bwd2(const float* x, const float* gamma, const float* beta, const float* dy, const float* c,
+                          float* g_x, float* g_gamma, float* g_beta, float* g_dy, int rows, int C, int groups, float eps,
+                          void* stream);
 /* g_weight[num_irreps] ACCUMULATED (the bias does not enter dx) */
 int eqf_layernorm_bwd2(const float* x, const float* weight, const float* dy, const float* c, float* g_x,
                        float* g_weight, float* g_dy, int rows, const eqf_irreps* irreps, float eps, void* stream);

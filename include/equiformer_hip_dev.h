@@ -36,8 +36,9 @@ int eqf_sfc_debug_buffer(void* device_u64x8);
  * numpy on these tables.  Returns the number of characters written or a negative error. */
 int eqf_sfcx_dev_plan(int kind, const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int E, int mode,
                       char* buf, int buflen);
-/* switches of the split-precision kernels: none at present (returns EQF_E_BADARG); A/B measurements of these kernels use variant
- * builds of the library (equiformer_amd/build.py --variant NAME -DEQF_...=...) */
+/* switches of the split-precision kernels: key 1 = the data gradient runs only the items of input degree (value - 1) / 2
+ * (0: all), to time one class of work items; A/B measurements of kernel variants use variant builds of the library
+ * (equiformer_amd/build.py --variant NAME -DEQF_...=...) */
 int eqf_sfcx_dev_set(int key, int value);
 /* csrc/gemmx.hip: key 0 = 0 selects the one-wave-per-tile kernels for node-row problems (default 1: LDS-tiled kernels for all) */
 int eqf_gemmx_dev_set(int key, int value);

@@ -100,6 +100,43 @@ def test_lnsilu_bwd2(C):
              [x, gamma, beta], [0], 7)
 
 
+@pytest.mark.parametrize("C,G", [(64, 7), (32, 3)])
+def test_lnsilu_group_bwd2(C, G):
+    """the radial bank's LayerNorm + SiLU: G feature vectors side by side in a row, each with its own gamma / beta
+    (eqf_lnsilu_group_bwd2, round 5) against the per-group restatement"""
+    from equiformer_amd import ops
+    g = torch.Generator().manual_seed(15)
+    x = _rows(203, C * G, 16, 1.3)
+    gamma = (torch.rand(C * G, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = torch.randn(C * G, generator=g, dtype=torch.float64).requires_grad_(True)
+
+    def ref(t, ga, be):
+        return torch.cat([so.ln_silu(t[:, k * C:(k + 1) * C], ga[k * C:(k + 1) * C], be[k * C:(k + 1) * C], 1e-5)
+                          for k in range(G)], dim=1)
+    _compare(lambda t, ga, be: ops.ln_silu(t, ga, be, 1e-5, groups=G), ref, [x, gamma, beta], [0], 17)
+
+
+@pytest.mark.parametrize("wide", [True, False])
+def test_grouped_linear_second_order(wide):
+    """G nn.Linear layers on the column blocks of one input in one launch (the radial bank's second and third layers):
+    differentiable grouped pieces under create_graph (ops._GroupedDgrad / _GroupedWgrad, round 5)"""
+    from equiformer_amd import ops
+    G, K = 5, 64
+    Ns = [64] * G if wide else [96, 64, 128, 64, 32]
+    g = torch.Generator().manual_seed(25)
+    x = _rows(157, G * K, 26, 0.7)
+    Ws = [(torch.randn(n, K, generator=g, dtype=torch.float64) * 0.2).requires_grad_(True) for n in Ns]
+    bs = [torch.randn(n, generator=g, dtype=torch.float64).requires_grad_(True) for n in Ns]
+
+    def hip(t, *p):
+        return ops.grouped_linear(t, K, list(p[:G]), list(p[G:]), wide)
+
+    def ref(t, *p):
+        outs = [t[:, k * K:(k + 1) * K] @ p[k].t() + p[G + k] for k in range(G)]
+        return torch.cat(outs, dim=1) if wide else tuple(outs)
+    _compare(hip, ref, [x] + Ws + bs, [0], 27)
+
+
 @pytest.mark.parametrize("irr", ["128x0e+64x1e+32x2e", "128x0e+64x1e+64x2e+32x3e", "32x0e+16x1e"])
 def test_layernorm_bwd2(irr):
     from equiformer_amd import ops

@@ -72,6 +72,11 @@ def run(name, irr, sh_irr, out_irr, n2, use_w, want_dM=False):
         fin = all(torch.isfinite(a).all().item() for a in (dx, dw) if a is not None)
         print("%-10s mode %d%s bwd_data   %7.1f us  (%5.1f TFLOP/s)  finite %s"
               % (name, mode, " dM" if want_dM else "", us, flops / us / 1e6, fin), flush=True)
+        if "--classes" in sys.argv:  # the launch with only the items of one input degree: that class's longest item
+            for dd in (1, 3, 5, 7):
+                L.eqf_sfcx_dev_set(1, dd)
+                print("%-10s            items of d1 = %d only: %7.1f us" % (name, dd, timeit(bw)), flush=True)
+            L.eqf_sfcx_dev_set(1, 0)
         if want_dM:
             continue
         fx = lambda: call("eqf_sfcx_fwd", P(x), P(M), P(w), table.c_ref, PK, None, None, P(o1), lay.c_ref, P(o2), n2, E,  # noqa: E731
