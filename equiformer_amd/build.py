@@ -85,9 +85,15 @@ def build(force=False, verbose=True, out=None, extra_flags=(), only=None):
     if out is not None:
         objdir = os.path.join(CSRC, ".variant_" + os.path.basename(out).replace("libequiformer_hip_", "").replace(".so", ""))
         os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "equiformer_hip.h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    incremental = out is None and not dev and os.environ.get("EQF_BUILD_ALL", "") != "1"
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
+        if (incremental and s != "rowops.hip" and os.path.exists(o)
+                and os.path.getmtime(o) > max(os.path.getmtime(os.path.join(CSRC, s)), newest_header)):
+            continue  # object newer than its source and every header (rowops.hip always: it carries the source hash)
         if only is not None and s not in only:
             base = os.path.join(CSRC, s.replace(".hip", ".o"))
             if os.path.exists(base):  # (variant builds: the product build's objects of untouched sources are reused)

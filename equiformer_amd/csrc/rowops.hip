@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// (Round 5 measured register-resident variants of the two kernels around this comment -- the row read once into 16 registers
+// per lane, per-segment sums formed from the registers: 23.5 us against 13.8 / 16.4 us at 2 304 rows.  The run-time loops
+// below are not the problem; the selects and index arithmetic of a segment-agnostic register layout cost more than the
+// re-reads from L1 they save.  Patch and A/B: profiles/r05/r05_k_*.)
 // Backward: dx = LN'(dy) (+ dres, the gradient arriving at the normalised sum from the residual branch); one wave per row.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ dy, const float* __restrict__ dres,
@@ -307,9 +311,20 @@ __global__ __launch_bounds__(256) void gate_bwd_cols_kernel(const float* __restr
       const float s = ir[c], sg = sigmoidf_(s);
       v = gr[c] * c_silu * (sg + s * sg * (1.f - sg));
     } else if (kind == 1) {
+      // (all 2 x (2l+1) loads of the gate column are requested before the first is used: with a run-time trip count every
+      // iteration was a dependent memory round trip -- 10 per row for a degree-2 gate, 80 per thread -- and the kernel took
+      // 27 us whatever the row count; indices past the degree are clamped and their products masked)
       const float gsig = sigmoidf_(ir[c]);
+      float ga[7], xa[7];
+#pragma unroll
+      for (int m = 0; m < 7; ++m) {
+        const int mm = min(m, d - 1);
+        ga[m] = gr[ia + mm * mul];
+        xa[m] = ir[ib + mm * mul];
+      }
       float acc = 0.f;
-      for (int m = 0; m < d; ++m) acc += gr[ia + m * mul] * ir[ib + m * mul];
+#pragma unroll
+      for (int m = 0; m < 7; ++m) acc += (m < d) ? ga[m] * xa[m] : 0.f;
       v = acc * c_sig * gsig * (1.f - gsig);
     } else {
       v = gr[ia] * c_sig * sigmoidf_(ir[ib]);

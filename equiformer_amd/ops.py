@@ -2105,11 +2105,12 @@ def _sfc_fwd(x, coupling, w, weight, bias, weight2, bias2, spec, mode=None, pack
     return out1, out2
 
 
-def _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, want_dM, mode=None, packed=None):
+def _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, want_dM, mode=None, packed=None, dM_out=None):
+    """dM_out: an existing d_coupling tensor the launch ADDS into (the kernels accumulate it with atomics anyway)"""
     E = x.shape[0]
     dx = (torch.empty_like if spec.in_covered else _zeros_like)(x)
     dw = torch.empty_like(w) if w is not None else None
-    dM = _zeros_like(coupling) if want_dM else None
+    dM = (dM_out if dM_out is not None else _zeros_like(coupling)) if want_dM else None
     if mode is None or not (spec.x_mask(mode) & 2):
         call("eqf_sfc_bwd_data", _p(x), _p(coupling), _p(w), spec.table.c_ref, _sfc_Wl(weight, spec), _p(weight2), _p(d1),
              spec.out_layout.c_ref, _p(d2), spec.n2, _p(dx), _p(dw), _p(dM), E, _stream())
@@ -2139,7 +2140,10 @@ class _SepFctpBwdData(Function):
     first-order kernels (forward, data-gradient, weight-gradient) evaluated with one argument substituted."""
 
     @staticmethod
-    def forward(ctx, x, coupling, w, weight, weight2, d1, d2, spec, mode):
+    def forward(ctx, x, coupling, w, weight, weight2, d1, d2, spec, mode, packed=None):
+        # packed: the bf16 planes of (weight, weight2) the forward of the operator made -- the same weights, so the data
+        # gradient here and the nine launches of the double backward reuse them (round 5: 39 -> 13 sfcx_pack launches per
+        # MD17 step, which is bound by its launch count)
         x, coupling, weight, d1 = _c(x), _c(coupling), _c(weight), _c(d1)
         w = _c(w) if w is not None else None
         weight2 = _c(weight2) if weight2 is not None else None
@@ -2149,7 +2153,8 @@ class _SepFctpBwdData(Function):
         ctx.spec = spec
         # the arithmetic of the forward this is the gradient of (passed in by _SepFctp.backward), not the global of the moment
         ctx.mode = mode
-        dx, dM, dw = _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, True, ctx.mode)
+        ctx.packed = packed if mode is not None else None
+        dx, dM, dw = _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, True, ctx.mode, ctx.packed)
         if w is None:
             return dx, dM
         return dx, dM, dw
@@ -2159,7 +2164,9 @@ class _SepFctpBwdData(Function):
     def backward(ctx, cx, cM, cw=None):
         x, M, w, weight, weight2, d1, d2 = ctx.saved_tensors
         spec, mode = ctx.spec, ctx.mode
-        packed = _sfc_pack(weight, weight2, spec, mode) if mode is not None else None
+        packed = ctx.packed
+        if packed is None and mode is not None:
+            packed = _sfc_pack(weight, weight2, spec, mode)
         need = ctx.needs_input_grad  # x, M, w, weight, weight2, d1, d2
         g_x = g_M = g_w = g_W = g_W2 = g_d1 = g_d2 = None
 
@@ -2184,17 +2191,18 @@ class _SepFctpBwdData(Function):
                 o1, o2 = _sfc_fwd(xs, Ms, ws, weight, None, weight2, None, spec, mode, packed)
                 g_d1, g_d2 = acc(g_d1, o1), acc(g_d2, o2)
             if need[0] or need[1] or need[2]:
-                dx_, dM_, dw_ = _sfc_bwd_data(xs, Ms, ws, weight, weight2, d1, d2, spec, which != "M" and need[1], mode,
-                                              packed)
+                want_M = which != "M" and need[1]
+                if want_M and g_M is None:
+                    g_M = _zeros_like(M)  # the kernels ADD their d_coupling: the launches accumulate in place, no torch add
+                dx_, _, dw_ = _sfc_bwd_data(xs, Ms, ws, weight, weight2, d1, d2, spec, want_M, mode, packed,
+                                            dM_out=g_M if want_M else None)
                 if which != "x" and need[0]:
                     g_x = acc(g_x, dx_)
-                if which != "M" and need[1]:
-                    g_M = acc(g_M, dM_)
                 if which != "w" and w is not None and need[2]:
                     g_w = acc(g_w, dw_)
             if g_W is not None:
                 _sfc_bwd_weight(xs, Ms, ws, d1, d2, spec, g_W, g_W2, mode)
-        return g_x, g_M, g_w, g_W, g_W2, g_d1, g_d2, None, None
+        return g_x, g_M, g_w, g_W, g_W2, g_d1, g_d2, None, None, None
 
 
 class _SepFctp(Function):
@@ -2236,7 +2244,8 @@ class _SepFctp(Function):
                 d1 = _zeros((E, spec.out_layout.dim), device=dev, dtype=torch.float32)
             if spec.n2 and d2 is None:
                 d2 = _zeros((E, spec.n2), device=dev, dtype=torch.float32)
-            outs = _SepFctpBwdData.apply(x, coupling, w, weight, weight2, d1, d2 if spec.n2 else None, spec, ctx.mode)
+            outs = _SepFctpBwdData.apply(x, coupling, w, weight, weight2, d1, d2 if spec.n2 else None, spec, ctx.mode,
+                                         ctx.packed)
             dx, dM = outs[0], outs[1]
             dw = outs[2] if w is not None else None
             # needs_input_grad is static (the parameters always "need" a gradient), so the weight / bias gradients
@@ -2347,7 +2356,7 @@ class _SepFctpGated(Function):
         if torch.is_grad_enabled():  # create_graph: the separate differentiable operators, on the re-materialised gate output
             note_create_graph()
             xg = gate(x_raw, S, gated_layout, c_silu, c_sig)
-            outs = _SepFctpBwdData.apply(xg, coupling, w, weight, None, d1, None, spec, mode)
+            outs = _SepFctpBwdData.apply(xg, coupling, w, weight, None, d1, None, spec, mode, ctx.packed)
             dxg, dM = outs[0], outs[1]
             dw = outs[2] if w is not None else None
             dx_raw = _GateBwd.apply(x_raw, dxg, S, gated_layout, c_silu, c_sig) if need[0] else None
