@@ -92,6 +92,9 @@ SIGNATURES = {
                                 c_int, c_int, c_fp],
     "eqf_sfcx_bwd_weight_gated": [c_fp, ctypes.POINTER(EqfGateIn), c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, _PP, c_int, c_int,
                                   c_fp],
+    "eqf_sfcx_bwd_weight_bias": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, c_fp, c_int, _PP, c_fp, c_fp, c_fp, c_int, c_int, c_fp],
+    "eqf_sfcx_bwd_weight_gated_bias": [c_fp, ctypes.POINTER(EqfGateIn), c_fp, c_fp, _P_PATHS, c_fp, _P_IRR, _PP, c_fp, c_int,
+                                       c_int, c_fp],
     "eqf_sfcx_pack": [_PP, c_fp, _P_PATHS, _P_IRR, c_int, c_int, c_fp, c_fp],
     "eqf_sfcx_fwd": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, c_fp, c_fp, _P_IRR, c_fp, c_int, c_int, c_int, c_fp],
     "eqf_sfcx_bwd_data": [c_fp, c_fp, c_fp, _P_PATHS, c_fp, c_fp, _P_IRR, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp],

@@ -2122,15 +2122,22 @@ def _sfc_bwd_data(x, coupling, w, weight, weight2, d1, d2, spec, want_dM, mode=N
     return dx, dM, dw
 
 
-def _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2, mode=None):
-    """dweight (flat) / dweight2, zero-initialised by the caller, are accumulated into."""
+def _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2, mode=None, dbias=None, dbias2=None):
+    """dweight (flat) / dweight2, zero-initialised by the caller, are accumulated into.  dbias / dbias2 (zero-initialised):
+    the bias gradients of the degree-0 linears, taken along by the split-precision launch.  Returns True if they were (the
+    exact-fp32 kernel does not: the caller then launches eqf_colsum)."""
     dWl = _sfc_Wl(dweight, spec)
     if mode is None or not (spec.x_mask(mode) & 4):
         call("eqf_sfc_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref, _p(d2),
              spec.n2, dWl, _p(dweight2), x.shape[0], _stream())
-    else:
-        call("eqf_sfcx_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref, _p(d2),
-             spec.n2, dWl, _p(dweight2), x.shape[0], mode, _stream())
+        return False
+    if (dbias is not None or dbias2 is not None) and 0 in [l3 for l3, _, _, _ in spec.degs]:
+        call("eqf_sfcx_bwd_weight_bias", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref, _p(d2),
+             spec.n2, dWl, _p(dweight2), _p(dbias), _p(dbias2), x.shape[0], mode, _stream())
+        return True
+    call("eqf_sfcx_bwd_weight", _p(x), _p(coupling), _p(w), spec.table.c_ref, _p(d1), spec.out_layout.c_ref, _p(d2),
+         spec.n2, dWl, _p(dweight2), x.shape[0], mode, _stream())
+    return False
 
 
 class _SepFctpBwdData(Function):
@@ -2303,15 +2310,17 @@ class _SepFctp(Function):
         if not _want_param_grads():  # force evaluation
             return dx, dM, dw, None, None, None, None, None
         if want_w:
+            dbias = flat[o2:o3] if want_b else None
+            dbias2 = flat[o3:] if want_b2 else None
+            bias_done = False
             if side is None and (need[3] or need[5]):
-                _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2, ctx.mode)
-            if want_b:
-                dbias = flat[o2:o3]
+                # (the bias gradients ride along in the weight-gradient launch: its degree-0 items stream those columns anyway)
+                bias_done = _sfc_bwd_weight(x, coupling, w, d1, d2, spec, dweight, dweight2, ctx.mode, dbias, dbias2)
+            if want_b and not bias_done:
                 j = spec.out_layout.seg_index(0)
                 call("eqf_colsum", _p(d1, spec.out_layout.offsets[j]), rows(1, spec.out_layout.dim, 0), E, n1_0,
                      _p(dbias), st)
-            if want_b2:
-                dbias2 = flat[o3:]
+            if want_b2 and not bias_done:
                 call("eqf_colsum", _p(d2), rows(1, spec.n2, 0), E, spec.n2, _p(dbias2), st)
         return dx, dM, dw, dweight, dbias, dweight2, dbias2, None
 
@@ -2389,11 +2398,11 @@ class _SepFctpGated(Function):
             n1_0 = spec.out_layout.mul_of(0)
             flat = _zeros(spec.weight_numel + (n1_0 if want_b else 0), device=dev, dtype=torch.float32)
             dweight = flat[:spec.weight_numel]
+            dbias = flat[spec.weight_numel:] if want_b else None
             if need[3]:
-                call("eqf_sfcx_bwd_weight_gated", _p(x_raw), ctypes.byref(ctx.gin), _p(coupling), _p(w), spec.table.c_ref,
-                     _p(d1), spec.out_layout.c_ref, _sfc_Wl(dweight, spec), E, mode, st)
-            if want_b:
-                dbias = flat[spec.weight_numel:]
+                call("eqf_sfcx_bwd_weight_gated_bias", _p(x_raw), ctypes.byref(ctx.gin), _p(coupling), _p(w), spec.table.c_ref,
+                     _p(d1), spec.out_layout.c_ref, _sfc_Wl(dweight, spec), _p(dbias), E, mode, st)
+            elif want_b:
                 o = spec.out_layout.offsets[spec.out_layout.seg_index(0)]
                 call("eqf_colsum", _p(d1, o), rows(1, spec.out_layout.dim, 0), E, n1_0, _p(dbias), st)
         return dx_raw, dM, dw, (dweight if need[3] else None), dbias, None, None

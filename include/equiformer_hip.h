@@ -314,6 +314,18 @@ int eqf_sfcx_bwd_weight_gated(const float* x_raw, const eqf_gate_in* gate, const
                               const eqf_dtp_paths* paths, const float* d_out1, const eqf_irreps* out1_irreps,
                               float* const* dWl, int E, int mode, void* stream);
 
+/* The two weight-gradient launches with the BIAS gradients of the operator's linears taken along: d_bias0[N1(0)] += column sums
+ * of the scalar block of d_out1, d_bias2[n2] += column sums of d_out2 (either may be NULL), accumulated by the work items
+ * that stream those columns anyway -- the separate eqf_colsum launch per bias re-read them (19 launches per QM9 step).
+ * [ref: the 0e bias of LinearRS / FullyConnectedTensorProductRescale, nets/tensor_product_rescale.py:125-136, whose gradient
+ *  autograd forms as dy.sum(0) for sep_act.lin, sep_alpha and sep_value.lin, nets/graph_attention_transformer.py:445-451] */
+int eqf_sfcx_bwd_weight_bias(const float* x, const float* coupling, const float* w, const eqf_dtp_paths* paths,
+                             const float* d_out1, const eqf_irreps* out1_irreps, const float* d_out2, int n2,
+                             float* const* dWl, float* dW2, float* d_bias0, float* d_bias2, int E, int mode, void* stream);
+int eqf_sfcx_bwd_weight_gated_bias(const float* x_raw, const eqf_gate_in* gate, const float* coupling, const float* w,
+                                   const eqf_dtp_paths* paths, const float* d_out1, const eqf_irreps* out1_irreps,
+                                   float* const* dWl, float* d_bias0, int E, int mode, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Row-local feature ops (nodes or edges)
  * ------------------------------------------------------------------------------------------- */
