@@ -34,10 +34,21 @@ __global__ __launch_bounds__(128) void segment_sum_kernel(const float* __restric
     const int D4 = D >> 2;
     for (int c = threadIdx.x; c < D4; c += blockDim.x) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int q = beg; q < end; ++q) {
-        const long row = perm ? perm[q] : q;
-        const float4 v = reinterpret_cast<const float4*>(x)[row * D4 + c];
-        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+      // four rows per step, their index and value loads in flight together (a row is ~11 entries: one load per iteration of a
+      // run-time loop made the kernel a chain of 2 x 11 dependent memory round trips); same summation order as before
+      for (int q = beg; q < end; q += 4) {
+        long row[4];
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int qq = min(q + j, end - 1);
+          row[j] = perm ? perm[qq] : qq;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const float4*>(x)[row[j] * D4 + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (q + j < end) acc.x += v[j].x, acc.y += v[j].y, acc.z += v[j].z, acc.w += v[j].w;
       }
       acc.x *= scale, acc.y *= scale, acc.z *= scale, acc.w *= scale;
       float4* o = reinterpret_cast<float4*>(out) + (long)n * D4 + c;
