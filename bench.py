@@ -56,6 +56,11 @@ def parse():
                          "energy + forces, force-loss train step through the second-order backward, 8 / 5 frames per GPU as "
                          "the reference scripts) | oc20 (config #5: IS2RE l1_256_nonlinear, 16 structures per GPU, periodic "
                          "graph built on the device)")
+    ap.add_argument("--prewarm-s", type=float, default=1.5,
+                    help="seconds of untimed steps BEFORE the W warm-up steps (setup, like building the model): a box that comes "
+                         "out of idle clocks ramps for a second or two -- profiles/r05/r05_drv_bench_default_cold_box.json "
+                         "has a headline region at 11 138 molecules/s followed, 3 s later in the same process, by a bf16 "
+                         "sub-record at 13 749.  0 disables; the timed region is still exactly K steps after W warm-up steps")
     ap.add_argument("--diag-static-graph", action="store_true",
                     help="DIAGNOSTIC, not a valid measurement: build the radius graph once outside the step (no host "
                          "synchronisation inside the step) -- shows how much of the step is the graph's sync bubble")
@@ -372,6 +377,12 @@ def measure(args, dev, rank, world, workload, mode, steps, warmup, regions=("sfc
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    prewarm = float(getattr(args, "prewarm_s", 0.0) or 0.0)
+    if prewarm > 0:
+        t_end = time.perf_counter() + prewarm
+        while time.perf_counter() < t_end:
+            step()
+            torch.cuda.synchronize()
     for _ in range(warmup):
         step()
     regions = list(regions)
@@ -414,7 +425,10 @@ def sub_record(args, dev, workload, mode, steps=10, warmup=3):
     try:
         a2 = argparse.Namespace(**vars(args))
         a2.batch, a2.atoms, a2.side = 128, 18, 6.5
-        wl, regs, loss = measure(a2, dev, 0, 1, workload, mode, steps, warmup, regions=("",))
+        # HIP events on the dominant SeparableFCTP kernel only, as in the headline region: the MD17 steps are launch-bound, and an
+        # event pair around each of their ~500 matrix-core launches cost the round-4 sub-records 10-15 % (standalone 462 frames/s
+        # vs 399 in the sub-record, profiles/r05)
+        wl, regs, loss = measure(a2, dev, 0, 1, workload, mode, steps, warmup, regions=("auto",))
         dt, prof, _ = regs[0]
         rec = {"workload": workload, "matrix_mode": mode, "dtype": "bf16" if mode == "bf16" else "f32",
                "model": wl["model_name"], "value": wl["units"] * steps / dt, "unit": WORKLOADS[workload]["unit"],
@@ -507,6 +521,7 @@ def main():
                 "edges_per_unit": n_edges / wl["units"], "parallelism": "dp%d" % world,
                 "final_loss": loss,
                 "matrix_mode": args.matrix_mode,
+                "prewarm_s": args.prewarm_s,
                 "arithmetic": ARITHMETIC[args.matrix_mode],
                 # node-row weight gradients queued during backward and launched in groups (library default; with N > 1 the
                 # reducer's hook flushes them before its collective): problems queued / grouped launches in the last region

@@ -50,7 +50,7 @@ def test_roofline_object_recomputes():
 
 
 def test_recorded_driver_style_line_is_self_consistent():
-    path = os.path.join(ROOT, "profiles", "r04", "r04_drv_bench_default.json")  # (round 5 adds a ("qm9", "fp32") sub-record)
+    path = os.path.join(ROOT, "profiles", "r05", "r05_drv_bench_default.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["unit"] == "molecules/s" and d["n_gpus"] == 1 and d["higher_is_better"] and d["scaling"] == "weak"
@@ -67,5 +67,12 @@ def test_recorded_driver_style_line_is_self_consistent():
     assert d["value"] / c["value"] > 100  # reported, not a target
     assert d["spread"]["values"][0] == d["value"] and len(d["spread"]["values"]) == 3
     subs = {(s["workload"], s["matrix_mode"]) for s in d["configs"]}
-    assert subs == {("qm9", "bf16"), ("oc20", "split"), ("md17_l2", "split"), ("md17_l3", "split")}
+    assert subs == {("qm9", "bf16"), ("qm9", "fp32"), ("oc20", "split"), ("md17_l2", "split"), ("md17_l3", "split")}
+    fp32 = [s for s in d["configs"] if s["matrix_mode"] == "fp32"][0]
+    assert fp32["dominant"]["peak"] == 157.3 and fp32["dtype"] == "f32"  # exact-fp32 MFMA everywhere: priced against its own peak
+    # the two kernels north_star names carry counter evidence of the same build (tools/gpu_profile.sh -> profiles/pmc_dominant.json)
+    ns = d["north_star_kernels"]
+    assert ns["scatter"]["traffic_over_algorithmic"] == pytest.approx(ns["scatter"]["traffic"] / ns["scatter"]["algorithmic_bytes_per_launch"])
+    assert 0.0 < ns["radial_mlp"]["widest_layer_kernel"]["mfma_busy"] < 1.0
+    assert d["config"]["deferred_weight_gradients"]["queued"] > 0
     assert [s for s in d["configs"] if s["matrix_mode"] == "bf16"][0]["dtype"] == "bf16"
