@@ -16,7 +16,7 @@ import bench  # noqa: E402
 
 wl_name = sys.argv[1] if len(sys.argv) > 1 else "md17_l2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-args = argparse.Namespace(batch=128, atoms=18, side=6.5, workload=wl_name)
+args = argparse.Namespace(batch=int(os.environ.get("EQF_HP_BATCH", "128")), atoms=18, side=6.5, workload=wl_name)
 dev = torch.device("cuda:0")
 from equiformer_amd import lib  # noqa: E402
 lib.load()
@@ -40,4 +40,4 @@ for _ in range(steps):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(45)

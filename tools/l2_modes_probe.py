@@ -10,3 +10,8 @@ for mode in ("split", "fp32", "split6", "split"):
             print(mode, ["%s %.2e" % (n.replace("blocks.", "b"), e) for e, n in worst[:4]], flush=True)
         except AssertionError as ex:
             print(mode, "ASSERT", str(ex)[:200])
+# the same without the radial bank (per-module radial MLPs: the round-4 second-order path)
+from equiformer_amd.nets import graph_attention_transformer as G
+G._Trunk.use_radial_bank = False
+_, worst = T._md17_fixture_case("md17_l2_bench8", "graph_attention_transformer_nonlinear_exp_l2_md17", True)
+print("split, radial bank off", ["%s %.2e" % (n.replace("blocks.", "b"), e) for e, n in worst[:4]], flush=True)
