@@ -380,9 +380,16 @@ def measure(args, dev, rank, world, workload, mode, steps, warmup, regions=("sfc
     prewarm = float(getattr(args, "prewarm_s", 0.0) or 0.0)
     if prewarm > 0:
         t_end = time.perf_counter() + prewarm
-        while time.perf_counter() < t_end:
+        while True:
             step()
             torch.cuda.synchronize()
+            go = time.perf_counter() < t_end
+            if world > 1:  # every rank runs the SAME number of steps (a step holds collectives): stop when the first rank is done
+                flag = torch.tensor([1.0 if go else 0.0], device=dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                go = flag.item() > 0.0
+            if not go:
+                break
     for _ in range(warmup):
         step()
     regions = list(regions)

@@ -202,7 +202,7 @@ def test_bench_gpus_2_runs_by_itself(tmp_path):
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
            "--repeats", "1", "--no-cpu-baseline", "--no-sub-records"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
