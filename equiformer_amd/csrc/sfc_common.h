@@ -61,6 +61,17 @@ __device__ __forceinline__ bool order_xy(const SfcOrder& o, int b, int& x, int& 
     y = b / o.nx, x = b - y * o.nx;
     return true;
   }
+  if (o.mode == 3) {
+    // XCD k = b % 8 owns the tiles x = 8 xi + k (all items of a tile still share one L2); inside an XCD the launch ids run
+    // ITEM-major, and the host sorts the items by cost, heaviest first: the long items of every tile start in the first round
+    // and the short ones fill the slots they free (round 6: with y fastest the last tiles' long items started last and the
+    // launch ended in a tail at low occupancy -- the forward's items take 23 / 50 / 55 us in a 150-us launch).  per_xcd =
+    // tiles per XCD.
+    const int k = b & 7, s = b >> 3;
+    y = s / o.per_xcd;
+    x = 8 * (s - y * o.per_xcd) + k;
+    return x < o.nx && y < o.ny;
+  }
   const int L = (o.mode == 1) ? (b & 7) * o.per_xcd + (b >> 3) : b;
   if (L >= o.nx * o.ny) return false;
   x = L / o.ny, y = L - x * o.ny;

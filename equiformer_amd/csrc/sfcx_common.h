@@ -271,6 +271,18 @@ inline int gate_map(const XGate& gt, const eqf_dtp_paths* P, int in_off, int mul
   return 0;
 }
 
+// items sorted by cost (heaviest first) by the planner; see order_xy mode 3
+#ifndef EQF_X_LPT
+#define EQF_X_LPT 1
+#endif
+inline SfcOrder lpt_order(int nx, int ny, int& nblocks) {
+  SfcOrder o;
+  o.mode = 3, o.nx = nx, o.ny = ny;
+  o.per_xcd = (nx + 7) / 8;
+  nblocks = 8 * o.per_xcd * ny;
+  return o;
+}
+
 constexpr int XB_MAXGRP = 12;
 constexpr int XB_MAXPATH = 12;
 struct XBPath {
@@ -370,10 +382,35 @@ inline int plan_bwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XBwdAr
   }
   if (ngrp == 0) return EQF_E_BADARG;
   ngrp_out = ngrp;
+#if EQF_X_LPT
+  {  // heaviest groups first (order_xy mode 3): matrix instructions of a group's paths + its register contraction
+    long cost[XB_MAXGRP];
+    for (int k = 0; k < ngrp; ++k) {
+      long c = 0;
+      for (int q = 0; q < A.grp[k].npath; ++q) {
+        const XBPath& Q = A.grp[k].p[q];
+        const int d3 = A.deg[Q.deg].d3;
+        c += (long)A.deg[Q.deg].nt * d3 * 5 * 32 + 64L * A.grp[k].d1 * d3 * 16 / 4 + 3000;
+      }
+      cost[k] = c;
+    }
+    for (int a = 1; a < ngrp; ++a)  // stable insertion sort, descending
+      for (int b = a; b > 0 && cost[b] > cost[b - 1]; --b) {
+        const XBGroup tg = A.grp[b];
+        A.grp[b] = A.grp[b - 1], A.grp[b - 1] = tg;
+        const long tc = cost[b];
+        cost[b] = cost[b - 1], cost[b - 1] = tc;
+      }
+  }
+#endif
   if ((C.x_ld | C.w_ld | C.ld1 | C.ld2) & 3) return EQF_E_UNSUPPORTED;  // the row-major tiles are read with 16-byte loads
   A.ms = (msmax + 3) & ~3;  // the transposition tile behind the coupling block stays 16-byte aligned
   lds = (size_t)(32 * A.ms + (1 + 5) * XT_FLOATS) * sizeof(float);  // coupling block + x / w / dx / dw tile + one d_out tile per m3
+#if EQF_X_LPT
+  A.ord = lpt_order(eqf_cdiv(C.E, 32), ngrp, nblk);
+#else
   A.ord = xcd_order(eqf_cdiv(C.E, 32), ngrp, nblk);
+#endif
   return 0;
 }
 

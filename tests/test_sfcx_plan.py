@@ -43,8 +43,13 @@ def _plan(kind, table, lay, n2, E, mode=0):
     return [ln.split() for ln in buf.value.decode().splitlines()]
 
 
-def _order_xy(b, nx, ny, per_xcd):
-    """sfc_common.h order_xy, mode 1 (XCD-aware)"""
+def _order_xy(b, nx, ny, per_xcd, mode=1):
+    """sfc_common.h order_xy, mode 1 (XCD-aware) / mode 3 (XCD owns the tiles 8 xi + k, item-major inside the XCD)"""
+    if mode == 3:
+        k, s = b & 7, b >> 3
+        y = s // per_xcd
+        x = 8 * (s - y * per_xcd) + k
+        return (x, y) if (x < nx and y < ny) else None
     Lg = (b & 7) * per_xcd + (b >> 3)
     if Lg >= nx * ny:
         return None
@@ -196,7 +201,7 @@ def replay_fwd(P, mode=0):
     seen = set()
     ctmax = {1: 3, 3: 2, 5: 1, 7: 1}
     for b in range(hdr["nblk"]):
-        xy = _order_xy(b, hdr["nx"], hdr["ny"], hdr["per_xcd"])
+        xy = _order_xy(b, hdr["nx"], hdr["ny"], hdr["per_xcd"], hdr["mode"])
         if xy is None:
             continue
         tile, y = xy
@@ -272,7 +277,7 @@ def replay_bwd(P, mode=0):
     CH = (Q[None, :] & 3) + 8 * (Q[None, :] >> 2) + 4 * HI[:, None]  # [lane, q] -> channel of the slab
     seen = set()
     for b in range(hdr["nblk"]):
-        xy = _order_xy(b, hdr["nx"], hdr["ny"], hdr["per_xcd"])
+        xy = _order_xy(b, hdr["nx"], hdr["ny"], hdr["per_xcd"], hdr["mode"])
         if xy is None:
             continue
         tile, gi = xy
@@ -342,7 +347,7 @@ def replay_wgrad(P, mode=0):
     assert ech % 32 == 0
     seen = set()
     for b in range(hdr["nblk"]):
-        xy = _order_xy(b, hdr["nx"], hdr["ny"], hdr["per_xcd"])
+        xy = _order_xy(b, hdr["nx"], hdr["ny"], hdr["per_xcd"], hdr["mode"])
         if xy is None:
             continue
         chunk, it = xy
