@@ -333,6 +333,139 @@ inline int max_deg(const SfcCommon& C) {
   return md;
 }
 
+// ------------------------------------------------------------------------------------------ forward: argument tables
+constexpr int X_MAXSEG = 4;   // input segments (l1 <= 3)
+constexpr int X_MAXP = 4;     // paths of one input segment into one output degree (the l2 values)
+
+struct XPath {
+  int w_off;    // first weight of the path in the w row
+  int kbase;    // first row of the path in W_l3 (channel index inside the degree's DTP output)
+  int m_rel;    // offset of the path's matrix inside the staged coupling block
+};
+struct XSeg {
+  int x_off;  // offset of the segment in the x row (the raw row when the input is gated)
+  int g_off;  // gated input: offset of the segment's gate scalars in the raw row (-1: scalar segment, -2: plain input)
+  short mul, d1, npath, m_len;
+  int m_off;  // offset of the block of the segment's matrices (all paths into this degree) in the coupling row
+  XPath p[X_MAXP];
+};
+struct XFwdArgs {
+  const float *x, *coupling, *w;
+  int x_ld, m_ld, w_ld, E;
+  float *o1, *o2;
+  int ld1, ld2;
+  const float *bias, *bias2;
+  const __bf16* packed;
+  int ms;  // row stride of the staged coupling block (odd)
+  int wave_lds;  // floats of LDS per wave (two waves per workgroup on small graphs: coupling block / partial-sum hand-over)
+  XGate gate;
+  SfcOrder ord;  // nx = edge tiles, ny = (degree, column group) items
+  struct Deg {
+    int d3, N1, Ncat, out1_off, cttot, nseg;
+    long pf;
+    XSeg seg[X_MAXSEG];
+  } deg[SFC_MAX_DEG];
+  signed char y_deg[16], y_ct0[16], y_ct[16];
+#if EQF_XTRACE
+  unsigned long long* trace;  // dev build: per-step clock samples of the first workgroups (tools/sfcx_trace.py)
+#endif
+};
+
+// column tiles per wave item: 3 / 2 / 1 accumulator tiles per row tile (48 / 96 / 80+ accumulator registers); with 4 tiles
+// for d3 == 1 the forward no longer fits 256 registers (2 waves per SIMD)
+__host__ __device__ constexpr int x_ctmax(int d3) { return d3 == 1 ? 3 : (d3 == 3 ? 2 : 1); }
+
+inline int plan_fwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XFwdArgs& A, int& nblk, size_t& lds,
+             const XGate* gate = nullptr) {
+  if (!fits32(C)) return EQF_E_UNSUPPORTED;
+  PkDeg pk[SFC_MAX_DEG];
+  pack_layout(C, mode_npw(mode), pk);
+  memset(&A, 0, sizeof A);
+  A.x = C.x, A.coupling = C.coupling, A.w = C.w;
+  A.x_ld = C.x_ld, A.m_ld = C.m_ld, A.w_ld = C.w_ld, A.E = C.E;
+  A.o1 = C.o1, A.o2 = C.o2, A.ld1 = C.ld1, A.ld2 = C.ld2;
+  if (gate) A.gate = *gate;
+  int ny = 0, msmax = 1;
+  for (int d = 0; d < C.ndeg; ++d) {
+    const SfcDeg& D = C.deg[d];
+    XFwdArgs::Deg& X = A.deg[d];
+    X.d3 = D.d3, X.N1 = D.N1, X.Ncat = D.Ncat, X.out1_off = D.out1_off, X.cttot = D.Ncat / 32, X.pf = pk[d].pf;
+    X.nseg = 0;
+    // input segments in path (creation) order; the matrices of one segment's paths into this degree are contiguous
+    for (int p = 0; p < P->npaths; ++p) {
+      if (P->l3[p] != D.l3) continue;
+      int si = -1;
+      for (int s = 0; s < X.nseg; ++s)
+        if (X.seg[s].x_off == P->in_off[p]) si = s;
+      if (si < 0) {
+        if (X.nseg >= X_MAXSEG) return EQF_E_UNSUPPORTED;
+        si = X.nseg++;
+        XSeg& S = X.seg[si];
+        S.x_off = P->in_off[p], S.mul = (short)P->mul[p], S.d1 = (short)(2 * P->l1[p] + 1);
+        S.npath = 0, S.m_off = P->m_off[p], S.m_len = 0;
+        S.g_off = -2;
+      }
+      XSeg& S = X.seg[si];
+      if (S.npath >= X_MAXP || P->mul[p] % 16 != 0) return EQF_E_UNSUPPORTED;
+      if (P->m_off[p] != S.m_off + S.m_len) return EQF_E_UNSUPPORTED;  // not contiguous (never with layout.DtpTable)
+      XPath& Q = S.p[S.npath++];
+      Q.w_off = P->w_off[p], Q.kbase = P->out_ch[p], Q.m_rel = S.m_len;
+      S.m_len = (short)(S.m_len + S.d1 * D.d3);
+      if ((S.m_len | 1) > msmax) msmax = S.m_len | 1;
+    }
+    const int ctm = x_ctmax(D.d3);
+    const int ng = eqf_cdiv(X.cttot, ctm), cps = eqf_cdiv(X.cttot, ng);
+    for (int k = 0; k < ng; ++k) {
+      if (ny >= 16) return EQF_E_UNSUPPORTED;
+      const int c0 = k * cps, cn = (X.cttot - c0 < cps) ? X.cttot - c0 : cps;
+      if (cn <= 0) continue;
+      A.y_deg[ny] = (signed char)d, A.y_ct0[ny] = (signed char)c0, A.y_ct[ny] = (signed char)cn;
+      ++ny;
+    }
+  }
+  if (A.gate.on)  // input rows = the gate's input: data and gate-scalar offsets of every segment in the raw row
+    for (int d = 0; d < C.ndeg; ++d)
+      for (int si = 0; si < A.deg[d].nseg; ++si) {
+        XSeg& S = A.deg[d].seg[si];
+        int raw_off = 0, g_off = -2;
+        const int grc = gate_map(A.gate, P, S.x_off, S.mul, S.d1, raw_off, g_off);
+        if (grc) return grc;
+        S.x_off = raw_off, S.g_off = g_off;
+      }
+  A.ms = msmax;
+  lds = ((size_t)32 * msmax * sizeof(float) + 15) & ~(size_t)15;
+  if (lds > 64 * 1024) return EQF_E_UNSUPPORTED;
+  A.wave_lds = (int)(lds / sizeof(float));
+  // Launch order (round 6, profiles/r06/r06_b_lpt_touch_ab.txt): the operator without per-edge weights (sep_value: 4 items per
+  // tile, operands from L2) gains 25 % from heaviest-items-first (124 -> 93 us at E = 25 354); the one that streams w [E, 960]
+  // (sep_act: 6 items per tile) loses 3 % -- its items no longer meet their tile's x / coupling rows in L2 -- and keeps the
+  // tile-major order.
+  if (EQF_X_LPT && C.w == nullptr) {
+    // cost of an item = steps x (operand wait + generation + matrix instructions of a step), fitted to the traced steps of
+    // profiles/r03/r03_s_what_bounds_the_forward.md
+    long cost[16];
+    for (int y = 0; y < ny; ++y) {
+      const XFwdArgs::Deg& X = A.deg[A.y_deg[y]];
+      long steps = 0;
+      for (int si = 0; si < X.nseg; ++si) steps += (long)X.seg[si].npath * (X.seg[si].mul / 16);
+      cost[y] = steps * (2500 + 500 * X.d3 + 170 * X.d3 * A.y_ct[y]);
+    }
+    for (int a = 1; a < ny; ++a)
+      for (int b = a; b > 0 && cost[b] > cost[b - 1]; --b) {
+        const signed char t0 = A.y_deg[b], t1 = A.y_ct0[b], t2 = A.y_ct[b];
+        A.y_deg[b] = A.y_deg[b - 1], A.y_ct0[b] = A.y_ct0[b - 1], A.y_ct[b] = A.y_ct[b - 1];
+        A.y_deg[b - 1] = t0, A.y_ct0[b - 1] = t1, A.y_ct[b - 1] = t2;
+        const long tc = cost[b];
+        cost[b] = cost[b - 1], cost[b - 1] = tc;
+      }
+    A.ord = lpt_order(eqf_cdiv(C.E, 32), ny, nblk);
+  } else {
+    A.ord = xcd_order(eqf_cdiv(C.E, 32), ny, nblk);
+  }
+  return 0;
+}
+
+
 inline int plan_bwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XBwdArgs& A, int& nblk, size_t& lds, int& ngrp_out,
                     const XGate* gate = nullptr) {
   if (!fits32(C)) return EQF_E_UNSUPPORTED;
@@ -415,3 +548,7 @@ inline int plan_bwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XBwdAr
 }
 
 }  // namespace
+
+// csrc/sfcy.hip: the multi-wave forward (round 6).  EQF_E_UNSUPPORTED: shape outside its tables, nothing launched.
+int sfcy_fwd_launch(const sfc::SfcCommon* C, const eqf_dtp_paths* paths, int mode, int gate_on, int gS, int gG, float c_silu,
+                    float c_sig, const float* bias0, const float* bias2, const void* packed, void* stream);
