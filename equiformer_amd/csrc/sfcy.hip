@@ -74,33 +74,30 @@ struct YFwdArgs {
 
 typedef __attribute__((address_space(3))) float lds_float;
 
-// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to lds_dst + 16 lane (wave-uniform byte address in M0)
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
-  // (the destination is wave-uniform by construction, but hipcc keeps loop-carried copies of it in VGPRs and then cannot
-  // satisfy an "s" constraint: it is read back with v_readfirstlane inside the statement)
-  unsigned keep, dst;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_nop 0\n\tv_readfirstlane_b32 %1, %3\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep), "=&s"(dst)
-      : "v"(gsrc), "v"(lds_dst_uniform)
-      : "memory");
+// LDS-DMA: 64 lanes x 16 bytes from sbase + voff (scalar 64-bit base, per-lane 32-bit byte offset) to LDS byte address lds_dst
+// + 16 lane.  M0 carries the LDS address; hipcc reserves M0 but holds nothing in it across statements of this kernel (no
+// movrel / sendmsg / GWS), so it is written and left.  Five issue slots per DMA including the two scalar adds of the caller
+// (the first version -- per-lane 64-bit pointers, M0 saved and restored, destination through v_readfirstlane -- took ~100
+// cycles of a loader wave per DMA: profiles/r06/r06_g_*).
+__device__ __forceinline__ void glds16(const void* sbase, const unsigned voff, const unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst)
+               : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
-// at most n DMA instructions of this wave still in flight (n even, <= 14: two w pieces + up to 2 (5 + 1) x pieces)
+// at most n DMA instructions of a loader wave still in flight (n even, <= 14: two w pieces + up to 2 (5 + 1) x pieces)
 __device__ __forceinline__ void wait_vmcnt(const int n) {
-  switch (n) {
+  switch (n >> 1) {
     case 0: wait_vm<0>(); break;
-    case 2: wait_vm<2>(); break;
-    case 4: wait_vm<4>(); break;
-    case 6: wait_vm<6>(); break;
-    case 8: wait_vm<8>(); break;
-    case 10: wait_vm<10>(); break;
-    case 12: wait_vm<12>(); break;
-    case 14: wait_vm<14>(); break;
+    case 1: wait_vm<2>(); break;
+    case 2: wait_vm<4>(); break;
+    case 3: wait_vm<6>(); break;
+    case 4: wait_vm<8>(); break;
+    case 5: wait_vm<10>(); break;
+    case 6: wait_vm<12>(); break;
+    case 7: wait_vm<14>(); break;
     default: wait_vm<0>(); break;
   }
 }
@@ -108,79 +105,201 @@ __device__ __forceinline__ void wait_vmcnt(const int n) {
 // One step of an item = (input segment, 16-channel chunk, path).  The table of an item's steps is built once per workgroup in
 // LDS (thread t: step t) and read back one entry per iteration with a broadcast ds_read + v_readfirstlane: walking the
 // segment / path tables of the kernarg segment instead cost ~30 dependent scalar loads per step, each behind an
-// s_waitcnt lgkmcnt(0) that also drains the LDS reads in flight (profiles/r06/r06_d_*: 73 of 183 us with everything else off).
+// s_waitcnt lgkmcnt(0) that also drains the LDS reads in flight (profiles/r06/r06_d_*).
 struct YStep {
   int x_off;   // offset of the chunk's first component in the x row (segment offset + c)
   int w_off;   // offset of the step's 16 weights in the w row
   int kt;      // 16-row block of W_l3: (kbase + c) / 16
   int m_rel;   // offset of the path's matrix in the staged coupling block
-  int flags;   // bit 0: first step of a chunk, bit 1: first step of a segment, bit 2: x slot of the chunk; bits 4-7: d1
-  int mul;     // multiplicity of the segment (stride between x components)
+  int flags;   // bit 0: first step of a chunk, bit 1: first step of a segment, bit 2: x slot of the chunk, bit 3: the chunk's x is
+               // requested ONE iteration ahead instead of two (its slot is read until then); bits 4-7: d1; bits 8-23: multiplicity
   int g_off;   // gated input: offset of the chunk's gate scalars in the raw row (-1 scalar segment, -2 plain)
   int m_blk;   // coupling block of the segment: m_off | m_len << 16
+  int m_next;  // the same of the NEXT segment (0: none): fetched into registers while this segment runs
 };
 constexpr int Y_MAXSTEP = 64;
 constexpr int Y_TAB_BYTES = Y_MAXSTEP * (int)sizeof(YStep);
+constexpr int Y_MAXMLEN = 96;  // coupling floats per edge of one (segment, output degree) block: three 32-column pieces
 
-__device__ __forceinline__ YStep y_entry(const float* tab, const int s) {
-  const int4* const p = reinterpret_cast<const int4*>(tab) + 2 * s;  // uniform address: broadcast read
-  const int4 a = p[0], b = p[1];
+__device__ __forceinline__ YStep y_unpack(const int4 a, const int4 b) {
   YStep e;
   e.x_off = __builtin_amdgcn_readfirstlane(a.x), e.w_off = __builtin_amdgcn_readfirstlane(a.y);
   e.kt = __builtin_amdgcn_readfirstlane(a.z), e.m_rel = __builtin_amdgcn_readfirstlane(a.w);
-  e.flags = __builtin_amdgcn_readfirstlane(b.x), e.mul = __builtin_amdgcn_readfirstlane(b.y);
-  e.g_off = __builtin_amdgcn_readfirstlane(b.z), e.m_blk = __builtin_amdgcn_readfirstlane(b.w);
+  e.flags = __builtin_amdgcn_readfirstlane(b.x), e.g_off = __builtin_amdgcn_readfirstlane(b.y);
+  e.m_blk = __builtin_amdgcn_readfirstlane(b.z), e.m_next = __builtin_amdgcn_readfirstlane(b.w);
   return e;
 }
+__device__ __forceinline__ YStep y_entry(const float* tab, const int s) {
+  const int4* const p = reinterpret_cast<const int4*>(tab) + 2 * s;  // uniform address: broadcast read
+  return y_unpack(p[0], p[1]);
+}
 
+// LDS map of a workgroup, bytes from the start of the dynamic segment:
+//   [step table][B slot 0][B slot 1] then per compute wave [x 0][x 1][w 0][w 1][w 2][M]
+struct YMap {
+  unsigned lds0, bs_off, bs_bytes, wv_off, wave_bytes, xs_bytes, ws_rel, mb_rel;
+};
+template <int NPW>
+__device__ __forceinline__ YMap y_map(const YFwdArgs& g, const YType& T) {
+  YMap m;
+  m.lds0 = (unsigned)(size_t)(lds_float*)sy_lds;
+  m.bs_off = Y_TAB_BYTES, m.bs_bytes = (unsigned)T.ct * NPW * 1024;
+  m.wv_off = m.bs_off + 2 * m.bs_bytes, m.wave_bytes = T.wave_bytes, m.xs_bytes = T.xs_bytes;
+  m.ws_rel = 2 * T.xs_bytes, m.mb_rel = m.ws_rel + (g.has_w ? 3 * 2048 : 0);
+  return m;
+}
+
+__device__ __forceinline__ void y_build_table(const XFwdArgs::Deg& D, const int nsteps) {
+  const int t = threadIdx.x;
+  if (t < nsteps) {
+    int t2 = t, si = 0, chunk0 = 0, first = 0;  // first: first step of the segment
+    for (; si < D.nseg - 1; ++si) {
+      const int n = D.seg[si].npath * (D.seg[si].mul >> 4);
+      if (t2 < n) break;
+      t2 -= n, first += n, chunk0 += D.seg[si].mul >> 4;
+    }
+    const XSeg& S = D.seg[si];
+    const int ch = t2 / S.npath, pi = t2 - ch * S.npath, c = 16 * ch;
+    // first step of the chunk two chunks back (same x slot): t - pi is this chunk's first step
+    int late = 0;
+    if (pi == 0 && chunk0 + ch >= 2) {
+      int back = 0;  // steps of the two chunks before this one
+      int sj = si, cj = ch;
+      for (int k = 0; k < 2; ++k) {
+        if (cj == 0) --sj, cj = D.seg[sj].mul >> 4;
+        --cj;
+        back += D.seg[sj].npath;
+      }
+      late = back < 3;
+    }
+    int4* const q = reinterpret_cast<int4*>(sy_lds) + 2 * t;
+    const int flags = (pi == 0 ? 1 : 0) | ((pi == 0 && ch == 0) ? 2 : 0) | (((chunk0 + ch) & 1) << 2) | (late << 3) | (S.d1 << 4) | (S.mul << 8);
+    const int m_next = si + 1 < D.nseg ? (D.seg[si + 1].m_off | (D.seg[si + 1].m_len << 16)) : 0;
+    q[0] = int4{S.x_off + c, S.p[pi].w_off + c, (S.p[pi].kbase + c) >> 4, S.p[pi].m_rel};
+    q[1] = int4{flags, S.g_off >= 0 ? S.g_off + c : S.g_off, S.m_off | (S.m_len << 16), m_next};
+  }
+  __syncthreads();
+}
+
+// --------------------------------------------------------------------------------------------------------- loader waves
+// Waves 4..7 of the workgroup: loader k issues the DMAs of tile k (x, w) and every fourth weight piece, and waits for them;
+// the compute waves only meet the loaders at the barrier that opens a step.  One loader beside one compute wave on every SIMD:
+// issuing a DMA costs its wave tens of cycles (the address unit takes the next request when it is done with the last), and in
+// the first version, where each wave loaded for itself, that was 45 k of an item's 130 k cycles in front of the step's
+// arithmetic (profiles/r06/r06_f_*); a single loader for four tiles could not keep up (r06_g_*: the compute waves of the
+// degree-0 items waited 2 500 cycles per step at the barrier).  Queue order per iteration s, after the barrier:
+//   B(s+1) | x of step s+1 if flagged late | x of step s+2 unless late | w(s+2)
+// and the wait that opens iteration s+1 leaves the last two groups in flight.
+template <int NPW>
+__device__ __forceinline__ void yf_loader(const YFwdArgs& g, const YType& T, const int grp, const int k) {
+  const XFwdArgs& f = g.f;
+  const XFwdArgs::Deg& D = f.deg[T.deg];
+  const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+  const int nsteps = T.nsteps, E = f.E;
+  const YMap m = y_map<NPW>(g, T);
+  const bool has_w = g.has_w != 0, gate_on = f.gate.on != 0;
+  const int e = min((grp * Y_WAVES + k) * 32 + r, E - 1);
+  const unsigned xoff = ((unsigned)e * f.x_ld + 8 * hi) * 4, woff = ((unsigned)e * f.w_ld + 8 * hi) * 4, boff = lane * 16;  // bytes
+  const char* const xg = reinterpret_cast<const char*>(f.x);
+  const char* const wg = reinterpret_cast<const char*>(f.w);
+  const char* const pf = reinterpret_cast<const char*>(f.packed + D.pf + (size_t)T.ct0 * NPW * 512);
+  const size_t kt_bytes = (size_t)D.cttot * NPW * 1024;
+  const int npiece = T.ct * NPW;
+  const unsigned my = m.lds0 + m.wv_off + (unsigned)k * m.wave_bytes;
+
+  auto issue_b = [&](const YStep& st, const int slot) __attribute__((always_inline)) {
+    const char* const src = pf + (size_t)st.kt * kt_bytes;
+    const unsigned dst = m.lds0 + m.bs_off + slot * m.bs_bytes;
+    for (int j = k; j < npiece; j += Y_WAVES) glds16(src + j * 1024, boff, dst + j * 1024);
+  };
+  auto issue_x = [&](const YStep& st) __attribute__((always_inline)) -> int {
+    const int d1 = (st.flags >> 4) & 15, mul = (st.flags >> 8) & 0xffff;
+    const bool gp = gate_on && st.g_off >= 0;
+    const char* const xb = xg + (size_t)st.x_off * 4;
+    const unsigned dst = my + ((st.flags >> 2) & 1) * m.xs_bytes;
+    auto go = [&](auto tag) __attribute__((always_inline)) {
+      constexpr int D1 = decltype(tag)::value;
+#pragma unroll
+      for (int i = 0; i < D1; ++i) {
+        glds16(xb + (size_t)(i * mul) * 4, xoff, dst + i * 2048);
+        glds16(xb + (size_t)(i * mul) * 4 + 16, xoff, dst + i * 2048 + 1024);
+      }
+      if (gp) {
+        const char* const gb = xg + (size_t)st.g_off * 4;
+        glds16(gb, xoff, dst + D1 * 2048);
+        glds16(gb + 16, xoff, dst + D1 * 2048 + 1024);
+      }
+    };
+    switch (d1) {
+      case 1: go(IC<1>()); break;
+      case 3: go(IC<3>()); break;
+      default: go(IC<5>()); break;
+    }
+    return 2 * (d1 + (gp ? 1 : 0));
+  };
+  auto issue_w = [&](const YStep& st, const int slot) __attribute__((always_inline)) {
+    const char* const wb = wg + (size_t)st.w_off * 4;
+    const unsigned dst = my + m.ws_rel + slot * 2048;
+    glds16(wb, woff, dst);
+    glds16(wb + 16, woff, dst + 1024);
+  };
+
+  YStep E1 = y_entry(sy_lds, min(1, nsteps - 1)), E2 = y_entry(sy_lds, min(2, nsteps - 1));
+  int n_tail = 0;  // DMA instructions issued after the ones the next step needs
+  {
+    const YStep E0 = y_entry(sy_lds, 0);
+    issue_x(E0);
+    if (has_w) issue_w(E0, 0);
+    issue_b(E0, 0);
+    if (nsteps > 1) {
+      if (E1.flags & 1) n_tail += issue_x(E1);
+      if (has_w) issue_w(E1, 1), n_tail += 2;
+    }
+  }
+  int s3 = 0;
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    wait_vmcnt(n_tail);
+    __builtin_amdgcn_s_barrier();
+    const int4* const tq = reinterpret_cast<const int4*>(sy_lds) + 2 * min(s + 3, nsteps - 1);
+    const int4 ta = tq[0], tb = tq[1];
+    n_tail = 0;
+    if (s + 1 < nsteps) {
+      issue_b(E1, (s + 1) & 1);
+      if ((E1.flags & 9) == 9 && s > 0) issue_x(E1);  // (step 1's x went out with the prologue)
+    }
+    if (s + 2 < nsteps) {
+      if ((E2.flags & 9) == 1) n_tail += issue_x(E2);
+      if (has_w) issue_w(E2, s3 == 0 ? 2 : s3 - 1), n_tail += 2;
+    }
+    s3 = s3 == 2 ? 0 : s3 + 1;
+    E1 = E2, E2 = y_unpack(ta, tb);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------- compute waves
 template <int D3, int MODE>
-__device__ __forceinline__ void yf_item(const YFwdArgs& g, const YType& T, const int grp) {
+__device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, const int grp, const int wave) {
   constexpr int CTM = y_ctmax(D3), NPA = Planes<MODE>::A, NPW = Planes<MODE>::W, XD = 5;
   const XFwdArgs& f = g.f;
   const XFwdArgs::Deg& D = f.deg[T.deg];
   const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int e0 = (grp * Y_WAVES + wave) * 32;  // (tiles past the end run on clamped rows and store nothing)
-  const bool valid = e0 + r < f.E;
-  const unsigned er = valid ? e0 + r : f.E - 1;
-  const int CT = T.ct, ct0 = T.ct0, nsteps = T.nsteps;
+  const int CT = T.ct, ct0 = T.ct0, nsteps = T.nsteps, E = f.E;
+  const bool valid = e0 + r < E;
 #if EQF_Y_TRACE
   long long yt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long yt_last = clock64();
   const long long yt_begin = yt_last;
 #endif
-
-  // LDS map, bytes from the start of the dynamic segment: [step table][B slot 0][B slot 1] then per wave
-  // [x 0][x 1][w 0][w 1][w 2][M]
-  const unsigned lds0 = (unsigned)(size_t)(lds_float*)sy_lds;
-  const unsigned bs_bytes = (unsigned)CT * NPW * 1024;
-  const unsigned bs_off = Y_TAB_BYTES;
-  const unsigned wv_off = bs_off + 2 * bs_bytes + (unsigned)wave * T.wave_bytes;
-  const unsigned xs_off = wv_off, ws_off = xs_off + 2 * T.xs_bytes, mb_off = ws_off + (g.has_w ? 3 * 2048 : 0);
-  float* const Mt = sy_lds + (mb_off >> 2);
+  const YMap m = y_map<NPW>(g, T);
+  const unsigned wv = m.wv_off + (unsigned)wave * m.wave_bytes;
+  float* const Mt = sy_lds + ((wv + m.mb_rel) >> 2);
   const int MS = T.ms;
-
-  {  // step table: thread t builds step t
-    const int t = threadIdx.x;
-    if (t < nsteps) {
-      int t2 = t, si = 0, chunk0 = 0;
-      for (; si < D.nseg - 1; ++si) {
-        const int n = D.seg[si].npath * (D.seg[si].mul >> 4);
-        if (t2 < n) break;
-        t2 -= n, chunk0 += D.seg[si].mul >> 4;
-      }
-      const XSeg& S = D.seg[si];
-      const int ch = t2 / S.npath, pi = t2 - ch * S.npath, c = 16 * ch;
-      YStep e;
-      e.x_off = S.x_off + c, e.w_off = S.p[pi].w_off + c, e.kt = (S.p[pi].kbase + c) >> 4, e.m_rel = S.p[pi].m_rel;
-      e.flags = (pi == 0 ? 1 : 0) | ((pi == 0 && ch == 0) ? 2 : 0) | (((chunk0 + ch) & 1) << 2) | (S.d1 << 4);
-      e.mul = S.mul, e.g_off = S.g_off >= 0 ? S.g_off + c : S.g_off, e.m_blk = S.m_off | (S.m_len << 16);
-      int4* const q = reinterpret_cast<int4*>(sy_lds) + 2 * t;
-      q[0] = int4{e.x_off, e.w_off, e.kt, e.m_rel};
-      q[1] = int4{e.flags, e.mul, e.g_off, e.m_blk};
-    }
-    __syncthreads();
-  }
+  const bool has_w = g.has_w != 0, gate_on = f.gate.on != 0;
+  const float c_silu = f.gate.c_silu, c_sig = f.gate.c_sig;
+  const float* const cpl = f.coupling;
+  const unsigned m_ld = f.m_ld;
 
   f32x16 acc[D3][CTM];
 #pragma unroll
@@ -190,82 +309,27 @@ __device__ __forceinline__ void yf_item(const YFwdArgs& g, const YType& T, const
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[m3][ct][q] = 0.f;
 
-  const __bf16* const pf = f.packed + D.pf + (size_t)ct0 * NPW * 512 + lane * 8;
-  const unsigned kt_stride = (unsigned)D.cttot * NPW * 512;
-  const int npiece = CT * NPW;
-  const unsigned xrow = er * f.x_ld + 8 * hi, wrow = er * f.w_ld + 8 * hi;
-  const bool has_w = g.has_w != 0, gate_on = f.gate.on != 0;
-  // loop-invariant arguments by value (read through the kernarg pointer they would be re-loaded after every asm statement)
-  const float c_silu = f.gate.c_silu, c_sig = f.gate.c_sig;
-  const float* const cpl = f.coupling;
-  const float* const xg = f.x;
-  const float* const wg = f.w;
-  const unsigned m_ld = f.m_ld;
-  const int E = f.E, xs_bytes = T.xs_bytes;
-
-  // ---- DMA issue (all addresses: uniform base + 32-bit lane offset; the host rejects tensors of >= 2^31 elements)
-  auto issue_b = [&](const YStep& e, const int slot) __attribute__((always_inline)) {
-    const __bf16* const src = pf + (size_t)e.kt * kt_stride;
-    const unsigned dst = lds0 + bs_off + slot * bs_bytes;
-    for (int j = wave; j < npiece; j += Y_WAVES) glds16(src + j * 512, dst + j * 1024);
-  };
-  auto issue_x = [&](const YStep& e) __attribute__((always_inline)) -> int {
-    const float* const xb = xg + e.x_off + xrow;
-    unsigned dst = lds0 + xs_off + ((e.flags >> 2) & 1) * xs_bytes;
-    const int d1 = (e.flags >> 4) & 15;
-    int n = 0;
-    for (int i = 0; i < d1; ++i, dst += 2048, n += 2) {
-      glds16(xb + i * e.mul, dst);
-      glds16(xb + i * e.mul + 4, dst + 1024);
-    }
-    if (gate_on && e.g_off >= 0) {
-      const float* const gb = xg + e.g_off + xrow;
-      glds16(gb, dst);
-      glds16(gb + 4, dst + 1024);
-      n += 2;
-    }
-    return n;
-  };
-  auto issue_w = [&](const YStep& e, const int slot) __attribute__((always_inline)) {
-    const float* const wb = wg + e.w_off + wrow;
-    const unsigned dst = lds0 + ws_off + slot * 2048;
-    glds16(wb, dst);
-    glds16(wb + 4, dst + 1024);
-  };
-
-  // E0 / E1 / E2: the entries of steps s, s + 1, s + 2 (clamped to the last step: never used past it)
-  YStep E0 = y_entry(sy_lds, 0), E1 = y_entry(sy_lds, min(1, nsteps - 1)), E2 = y_entry(sy_lds, min(2, nsteps - 1));
-  // prologue: queue = x(chunk of step 0), w(0), B(0), x(chunk of step 1)?, w(1)
-  int nw_last = 0, nx_last = 0;
-  issue_x(E0);
-  if (has_w) issue_w(E0, 0);
-  issue_b(E0, 0);
-  if (nsteps > 1) {
-    if (E1.flags & 1) nx_last = issue_x(E1);
-    if (has_w) issue_w(E1, 1), nw_last = 2;
-  }
-
+  YStep E0 = y_entry(sy_lds, 0);
+  YStep E1 = y_entry(sy_lds, min(1, nsteps - 1));
   float xf[XD][8];
   int s3 = 0;  // s % 3
-  YT_STAMP(0);  // table + prologue issue
+  YT_STAMP(0);
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
     const bool chunk_first = (E0.flags & 1) != 0;
     const int d1 = (E0.flags >> 4) & 15;
-    wait_vmcnt(nw_last + nx_last);
-    YT_STAMP(1);  // operand wait
     __builtin_amdgcn_s_barrier();
     YT_STAMP(2);  // barrier
-    // the entry of step s + 3 (a broadcast LDS read, consumed at the end of the iteration)
-    const int4* const tq = reinterpret_cast<const int4*>(sy_lds) + 2 * min(s + 3, nsteps - 1);
+    const int4* const tq = reinterpret_cast<const int4*>(sy_lds) + 2 * min(s + 2, nsteps - 1);
     const int4 ta = tq[0], tb = tq[1];
-    if ((E0.flags & 2) && (!(EQF_Y_ABLATE & 4) || s == 0)) {  // a new input segment: its coupling block (ordinary loads; three times per item)
+    if (E0.flags & 2) {  // a new input segment: its coupling block (ordinary loads -- the compute waves have no DMA in flight --
+                         // whose latency is exposed three times per item: the next thing to move to the loader)
       wave_lds_order();
       stage_m(Mt, MS, cpl + (E0.m_blk & 0xffff), m_ld, e0, E - 1, E0.m_blk >> 16, r, hi);
       wave_lds_order();
     }
-    if (chunk_first) {  // this chunk's x rows leave their slot before the DMA of the chunk after next may land in it
-      const float* const xs = sy_lds + ((xs_off + ((E0.flags >> 2) & 1) * xs_bytes) >> 2) + lane * 4;
+    if (chunk_first) {
+      const float* const xs = sy_lds + ((wv + ((E0.flags >> 2) & 1) * m.xs_bytes) >> 2) + lane * 4;
       auto ldx = [&](auto tag) __attribute__((always_inline)) {
         constexpr int D1 = decltype(tag)::value;
 #pragma unroll
@@ -301,25 +365,11 @@ __device__ __forceinline__ void yf_item(const YFwdArgs& g, const YType& T, const
         case 3: ldx(IC<3>()); break;
         default: ldx(IC<5>()); break;
       }
-#pragma unroll
-      for (int i = 0; i < XD; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(xf[i][j]));  // (the reads have returned: lgkmcnt(0) before the DMAs below)
     }
-    nx_last = 0, nw_last = 0;
-    if (s + 1 < nsteps && !(EQF_Y_ABLATE & 32)) issue_b(E1, (s + 1) & 1);
-    if (s + 2 < nsteps && !(EQF_Y_ABLATE & 16)) {
-      if (E2.flags & 1) nx_last = issue_x(E2);
-      if (has_w) {
-        issue_w(E2, s3 == 0 ? 2 : s3 - 1);  // (s + 2) % 3
-        nw_last = 2;
-      }
-    }
-
-    YT_STAMP(3);  // coupling block, x rows out of their slot, DMA issue
+    YT_STAMP(3);  // coupling block, x rows out of their slot
     float wf[8];
     if (has_w) {
-      const float* const ws = sy_lds + ((ws_off + s3 * 2048) >> 2) + lane * 4;
+      const float* const ws = sy_lds + ((wv + m.ws_rel + s3 * 2048) >> 2) + lane * 4;
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(ws);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(ws + 256);
 #pragma unroll
@@ -329,7 +379,7 @@ __device__ __forceinline__ void yf_item(const YFwdArgs& g, const YType& T, const
       for (int j = 0; j < 8; ++j) wf[j] = valid ? 1.f : 0.f;
     }
     const float* const mp = Mt + r * MS + E0.m_rel;
-    const __bf16* const bs = reinterpret_cast<const __bf16*>(sy_lds) + ((bs_off + (s & 1) * bs_bytes) >> 1) + lane * 8;
+    const __bf16* const bs = reinterpret_cast<const __bf16*>(sy_lds) + ((m.bs_off + (s & 1) * m.bs_bytes) >> 1) + lane * 8;
 #pragma unroll
     for (int m3 = 0; m3 < D3; ++m3) {
       float a[8];
@@ -339,21 +389,16 @@ __device__ __forceinline__ void yf_item(const YFwdArgs& g, const YType& T, const
         for (int j = 0; j < 8; ++j) a[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < D1; ++i) {
-          const float m = mp[i * D3 + m3];
+          const float mm = mp[i * D3 + m3];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] = fmaf(m, xf[i][j], a[j]);
+          for (int j = 0; j < 8; ++j) a[j] = fmaf(mm, xf[i][j], a[j]);
         }
       };
-#if EQF_Y_ABLATE & 2
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = xf[0][j] + mp[m3];
-#else
       switch (d1) {
         case 1: gen(IC<1>()); break;
         case 3: gen(IC<3>()); break;
         default: gen(IC<5>()); break;
       }
-#endif
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] *= wf[j];
       bf16x8 pa[NPA];
@@ -364,32 +409,16 @@ __device__ __forceinline__ void yf_item(const YFwdArgs& g, const YType& T, const
         bf16x8 bw[NPW];
 #pragma unroll
         for (int pl = 0; pl < NPW; ++pl) bw[pl] = *reinterpret_cast<const bf16x8*>(bs + (cc * NPW + pl) * 512);
-#if EQF_Y_ABLATE & 1
-#pragma unroll
-        for (int pl = 0; pl < NPW; ++pl) asm volatile("" ::"v"(bw[pl]));
-#pragma unroll
-        for (int pl = 0; pl < NPA; ++pl) asm volatile("" ::"v"(pa[pl]));
-#else
         mma_terms<NPA, NPW>(pa, bw, acc[m3][ct]);
-#endif
       }
     }
-
     YT_STAMP(4);  // generation + matrix instructions (issue)
     s3 = s3 == 2 ? 0 : s3 + 1;
-    E0 = E1, E1 = E2;
-    E2.x_off = __builtin_amdgcn_readfirstlane(ta.x), E2.w_off = __builtin_amdgcn_readfirstlane(ta.y);
-    E2.kt = __builtin_amdgcn_readfirstlane(ta.z), E2.m_rel = __builtin_amdgcn_readfirstlane(ta.w);
-    E2.flags = __builtin_amdgcn_readfirstlane(tb.x), E2.mul = __builtin_amdgcn_readfirstlane(tb.y);
-    E2.g_off = __builtin_amdgcn_readfirstlane(tb.z), E2.m_blk = __builtin_amdgcn_readfirstlane(tb.w);
+    E0 = E1, E1 = y_unpack(ta, tb);
   }
 
-  // (the accumulators leave the loop IN the accumulator file: without this hipcc copies all of them to VGPRs at the end of every
-  // iteration -- 96 v_accvgpr_read per step, each waiting for the matrix instruction before it -- for the benefit of the stores)
-#pragma unroll
-  for (int m3 = 0; m3 < D3; ++m3)
-#pragma unroll
-    for (int ct = 0; ct < CTM; ++ct) asm volatile("" : "+a"(acc[m3][ct]));
+  // (two waves per SIMD -- a loader beside a compute wave -- so the register budget is 256 and hipcc keeps the accumulators in
+  // VGPRs: no accumulator-file copies.  With 512 registers it copied all of them to VGPRs at the end of every iteration.)
   YT_STAMP(5);  // accumulators retired
   // epilogue: accumulator register q of lane (r, hi) = row (edge) (q & 3) + 8 (q >> 2) + 4 hi, column r of the tile
 #pragma unroll
@@ -409,27 +438,33 @@ __device__ __forceinline__ void yf_item(const YFwdArgs& g, const YType& T, const
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hi;
-        if (e0 + row < f.E && !(EQF_Y_ABLATE & 8)) base[(unsigned)(e0 + row) * ld + (unsigned)(m3 * D.N1 + r)] = acc[m3][ct][q] + bv;
+        if (e0 + row < E) base[(unsigned)(e0 + row) * ld + (unsigned)(m3 * D.N1 + r)] = acc[m3][ct][q] + bv;
       }
   }
 #if EQF_Y_TRACE
   YT_STAMP(6);  // stores issued
-  if (grp == 3 && threadIdx.x == 0)
-    printf("ytrace d3 %d ct %d steps %d: total %lld | prologue %lld wait %lld barrier %lld stage+issue %lld compute %lld retire %lld stores %lld\n",
-           D3, CT, nsteps, clock64() - yt_begin, yt[0], yt[1], yt[2], yt[3], yt[4], yt[5], yt[6]);
+  if (grp == 3 && wave == 0 && lane == 0)
+    printf("ytrace d3 %d ct %d steps %d: total %lld | prologue %lld barrier %lld stage %lld compute %lld retire %lld stores %lld\n",
+           D3, CT, nsteps, clock64() - yt_begin, yt[0], yt[2], yt[3], yt[4], yt[5], yt[6]);
 #endif
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void sfcy_fwd_kernel(const YFwdArgs g_byval) {
+__global__ __launch_bounds__(128 * Y_WAVES, 2) void sfcy_fwd_kernel(const YFwdArgs g_byval) {
   KERNARG_IN_PLACE(YFwdArgs);
   // item-major launch order, heaviest item type first (the host sorts the types): grp fastest
   const int y = blockIdx.x / g.ngrp, grp = blockIdx.x - y * g.ngrp;
   const YType& T = g.type[y];
+  y_build_table(g.f.deg[T.deg], T.nsteps);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wave >= Y_WAVES) {
+    yf_loader<Planes<MODE>::W>(g, T, grp, wave - Y_WAVES);
+    return;
+  }
   switch (g.f.deg[T.deg].d3) {
-    case 1: yf_item<1, MODE>(g, T, grp); break;
-    case 3: yf_item<3, MODE>(g, T, grp); break;
-    default: yf_item<5, MODE>(g, T, grp); break;
+    case 1: yf_compute<1, MODE>(g, T, grp, wave); break;
+    case 3: yf_compute<3, MODE>(g, T, grp, wave); break;
+    default: yf_compute<5, MODE>(g, T, grp, wave); break;
   }
 }
 
@@ -462,7 +497,7 @@ int plan_yfwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, const XGate*
       steps += (long)S.npath * (S.mul / 16);
       for (int q = 0; q < S.npath; ++q)
         if ((S.p[q].w_off & 3) || (S.p[q].kbase & 15)) return EQF_E_UNSUPPORTED;
-      if (S.m_off > 0xffff || S.m_len > 0x7fff) return EQF_E_UNSUPPORTED;
+      if (S.m_off > 0xffff || S.m_len > Y_MAXMLEN || S.mul > 0xffff) return EQF_E_UNSUPPORTED;
     }
     const int ctm = y_ctmax(X.d3);
     const int ng = eqf_cdiv(X.cttot, ctm), cps = eqf_cdiv(X.cttot, ng);
@@ -524,7 +559,7 @@ int sfcy_fwd_launch(const sfc::SfcCommon* Cp, const eqf_dtp_paths* paths, int mo
         return EQF_E_UNSUPPORTED;                                                                                    \
       big_lds = true;                                                                                                \
     }                                                                                                                \
-    hipLaunchKernelGGL((sfcy_fwd_kernel<M>), dim3(nblk), dim3(64 * Y_WAVES), lds, st, A);                            \
+    hipLaunchKernelGGL((sfcy_fwd_kernel<M>), dim3(nblk), dim3(128 * Y_WAVES), lds, st, A);                            \
   } while (0)
   if (mode == 0) YF_LAUNCH(0);
   else if (mode == 1) YF_LAUNCH(1);
