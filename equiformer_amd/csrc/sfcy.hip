@@ -65,6 +65,7 @@ struct YType {
   int ms;          // row stride (floats, odd) of the staged coupling block
   int wave_bytes;  // LDS per wave: 2 x slots + 3 w slots + coupling block
   int nsteps;      // (segment, chunk, path) steps of the degree
+  int nst[3];      // ... of the segment of input degree 2 l1 + 1 = 1, 3, 5 (the segments run in this order)
 };
 struct YFwdArgs {
   XFwdArgs f;  // tensors, per-degree segment / path tables, gate (plan_fwd)
@@ -278,9 +279,33 @@ __device__ __forceinline__ void yf_loader(const YFwdArgs& g, const YType& T, con
 }
 
 // -------------------------------------------------------------------------------------------------------- compute waves
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// split_planes of sfcx_common.h with the conversions in PAIRS (v_cvt_pk_bf16_f32 takes two values): 24 instead of 32 vector
+// instructions per eight values and two planes; the same roundings, bit for bit
+template <int NP>
+__device__ __forceinline__ void split_planes_pk(const float (&v)[8], bf16x8 (&p)[NP]) {
+#pragma unroll
+  for (int jp = 0; jp < 4; ++jp) {
+    float r0 = v[2 * jp], r1 = v[2 * jp + 1];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const bf16x2 h = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
+      p[q][2 * jp] = h[0], p[q][2 * jp + 1] = h[1];
+      if (q + 1 < NP) r0 -= (float)h[0], r1 -= (float)h[1];
+    }
+  }
+}
+
+// The steps of an item run segment by segment, and the input degree of a segment only shapes the generation of the A values:
+// one loop per input degree (2 l1 + 1 = 1, 3, 5, in the order the planner guarantees), each with a branch-free step body --
+// generation, split and matrix instructions of all 2 l3 + 1 components in ONE basic block, so that hipcc's scheduler can put
+// the vector instructions of component m3 + 1 between the matrix instructions of m3.  (First version: a switch on the input
+// degree inside the m3 loop; a wave issues one instruction per ~4 cycles whatever its kind, and with the blocks cut at every
+// switch a step of the degree-2 item took 3 200 cycles for 320 vector + 25 matrix instructions: profiles/r06/r06_h_*.)
 template <int D3, int MODE>
 __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, const int grp, const int wave) {
-  constexpr int CTM = y_ctmax(D3), NPA = Planes<MODE>::A, NPW = Planes<MODE>::W, XD = 5;
+  constexpr int CTM = y_ctmax(D3), NPA = Planes<MODE>::A, NPW = Planes<MODE>::W;
   const XFwdArgs& f = g.f;
   const XFwdArgs::Deg& D = f.deg[T.deg];
   const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
@@ -311,27 +336,28 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
 
   YStep E0 = y_entry(sy_lds, 0);
   YStep E1 = y_entry(sy_lds, min(1, nsteps - 1));
-  float xf[XD][8];
-  int s3 = 0;  // s % 3
+  int s = 0, s3 = 0;  // s3 = s % 3
   YT_STAMP(0);
-#pragma unroll 1
-  for (int s = 0; s < nsteps; ++s) {
-    const bool chunk_first = (E0.flags & 1) != 0;
-    const int d1 = (E0.flags >> 4) & 15;
-    __builtin_amdgcn_s_barrier();
-    YT_STAMP(2);  // barrier
-    const int4* const tq = reinterpret_cast<const int4*>(sy_lds) + 2 * min(s + 2, nsteps - 1);
-    const int4 ta = tq[0], tb = tq[1];
-    if (E0.flags & 2) {  // a new input segment: its coupling block (ordinary loads -- the compute waves have no DMA in flight --
-                         // whose latency is exposed three times per item: the next thing to move to the loader)
+
+  auto run = [&](auto tag, const int nst) __attribute__((always_inline)) {
+    constexpr int D1 = decltype(tag)::value;
+    if (nst <= 0) return;
+    float xf[D1][8];
+    const int s_end = s + nst;
+    {  // the segment's coupling block (ordinary loads -- the compute waves have no DMA in flight -- whose latency is exposed
+       // up to three times per item: the next thing to move to the loaders)
       wave_lds_order();
       stage_m(Mt, MS, cpl + (E0.m_blk & 0xffff), m_ld, e0, E - 1, E0.m_blk >> 16, r, hi);
       wave_lds_order();
     }
-    if (chunk_first) {
-      const float* const xs = sy_lds + ((wv + ((E0.flags >> 2) & 1) * m.xs_bytes) >> 2) + lane * 4;
-      auto ldx = [&](auto tag) __attribute__((always_inline)) {
-        constexpr int D1 = decltype(tag)::value;
+#pragma unroll 1
+    for (; s < s_end; ++s) {
+      __builtin_amdgcn_s_barrier();
+      YT_STAMP(2);  // barrier
+      const int4* const tq = reinterpret_cast<const int4*>(sy_lds) + 2 * min(s + 2, nsteps - 1);
+      const int4 ta = tq[0], tb = tq[1];
+      if (E0.flags & 1) {  // first step of a chunk: its x rows out of their slot
+        const float* const xs = sy_lds + ((wv + ((E0.flags >> 2) & 1) * m.xs_bytes) >> 2) + lane * 4;
 #pragma unroll
         for (int i = 0; i < D1; ++i) {
           const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs + i * 512);
@@ -339,10 +365,6 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
 #pragma unroll
           for (int j = 0; j < 4; ++j) xf[i][j] = a0[j], xf[i][4 + j] = a1[j];
         }
-#pragma unroll
-        for (int i = D1; i < XD; ++i)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) xf[i][j] = 0.f;
         if (gate_on) {  // uniform: the rows are the gate's INPUT, activate / gate them here
           if (E0.g_off == -1) {
 #pragma unroll
@@ -359,63 +381,55 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
               for (int j = 0; j < 8; ++j) xf[i][j] *= sg[j];
           }
         }
-      };
-      switch (d1) {
-        case 1: ldx(IC<1>()); break;
-        case 3: ldx(IC<3>()); break;
-        default: ldx(IC<5>()); break;
       }
-    }
-    YT_STAMP(3);  // coupling block, x rows out of their slot
-    float wf[8];
-    if (has_w) {
-      const float* const ws = sy_lds + ((wv + m.ws_rel + s3 * 2048) >> 2) + lane * 4;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ws);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(ws + 256);
+      YT_STAMP(3);  // x rows out of their slot
+      float wf[8];
+      if (has_w) {
+        const float* const ws = sy_lds + ((wv + m.ws_rel + s3 * 2048) >> 2) + lane * 4;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ws);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ws + 256);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = valid ? a0[j] : 0.f, wf[4 + j] = valid ? a1[j] : 0.f;
-    } else {
+        for (int j = 0; j < 4; ++j) wf[j] = valid ? a0[j] : 0.f, wf[4 + j] = valid ? a1[j] : 0.f;
+      } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wf[j] = valid ? 1.f : 0.f;
-    }
-    const float* const mp = Mt + r * MS + E0.m_rel;
-    const __bf16* const bs = reinterpret_cast<const __bf16*>(sy_lds) + ((m.bs_off + (s & 1) * m.bs_bytes) >> 1) + lane * 8;
+        for (int j = 0; j < 8; ++j) wf[j] = valid ? 1.f : 0.f;
+      }
+      // this edge's matrix of the step's path, all of it up front: one LDS round trip per step instead of one per m3
+      const float* const mp = Mt + r * MS + E0.m_rel;
+      float mm[D1 * D3];
 #pragma unroll
-    for (int m3 = 0; m3 < D3; ++m3) {
-      float a[8];
-      auto gen = [&](auto tag) __attribute__((always_inline)) {
-        constexpr int D1 = decltype(tag)::value;
+      for (int k = 0; k < D1 * D3; ++k) mm[k] = mp[k];
+      const __bf16* const bs = reinterpret_cast<const __bf16*>(sy_lds) + ((m.bs_off + (s & 1) * m.bs_bytes) >> 1) + lane * 8;
+#pragma unroll
+      for (int m3 = 0; m3 < D3; ++m3) {
+        float a[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = 0.f;
 #pragma unroll
-        for (int i = 0; i < D1; ++i) {
-          const float mm = mp[i * D3 + m3];
+        for (int i = 0; i < D1; ++i)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] = fmaf(mm, xf[i][j], a[j]);
+          for (int j = 0; j < 8; ++j) a[j] = fmaf(mm[i * D3 + m3], xf[i][j], a[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] *= wf[j];
+        bf16x8 pa[NPA];
+        split_planes_pk<NPA>(a, pa);
+#pragma unroll
+        for (int ct = 0; ct < CTM; ++ct) {
+          const int cc = ct < CT ? ct : CT - 1;  // (tiles past CT re-read the last one; their accumulators are never stored)
+          bf16x8 bw[NPW];
+#pragma unroll
+          for (int pl = 0; pl < NPW; ++pl) bw[pl] = *reinterpret_cast<const bf16x8*>(bs + (cc * NPW + pl) * 512);
+          mma_terms<NPA, NPW>(pa, bw, acc[m3][ct]);
         }
-      };
-      switch (d1) {
-        case 1: gen(IC<1>()); break;
-        case 3: gen(IC<3>()); break;
-        default: gen(IC<5>()); break;
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] *= wf[j];
-      bf16x8 pa[NPA];
-      split_planes<NPA>(a, pa);
-#pragma unroll
-      for (int ct = 0; ct < CTM; ++ct) {
-        const int cc = ct < CT ? ct : CT - 1;  // (tiles past CT re-read the last one; their accumulators are never stored)
-        bf16x8 bw[NPW];
-#pragma unroll
-        for (int pl = 0; pl < NPW; ++pl) bw[pl] = *reinterpret_cast<const bf16x8*>(bs + (cc * NPW + pl) * 512);
-        mma_terms<NPA, NPW>(pa, bw, acc[m3][ct]);
-      }
+      YT_STAMP(4);  // generation + matrix instructions (issue)
+      s3 = s3 == 2 ? 0 : s3 + 1;
+      E0 = E1, E1 = y_unpack(ta, tb);
     }
-    YT_STAMP(4);  // generation + matrix instructions (issue)
-    s3 = s3 == 2 ? 0 : s3 + 1;
-    E0 = E1, E1 = y_unpack(ta, tb);
-  }
+  };
+  run(IC<1>(), T.nst[0]);
+  run(IC<3>(), T.nst[1]);
+  run(IC<5>(), T.nst[2]);
 
   // (two waves per SIMD -- a loader beside a compute wave -- so the register budget is 256 and hipcc keeps the accumulators in
   // VGPRs: no accumulator-file copies.  With 512 registers it copied all of them to VGPRs at the end of every iteration.)
@@ -486,9 +500,12 @@ int plan_yfwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, const XGate*
     if (X.d3 != 1 && X.d3 != 3 && X.d3 != 5) return EQF_E_UNSUPPORTED;
     int d1max = 1, mlen = 1, gpiece = 0;
     long steps = 0;
+    int nst[3] = {0, 0, 0};
     for (int si = 0; si < X.nseg; ++si) {
       const XSeg& S = X.seg[si];
       if (S.d1 != 1 && S.d1 != 3 && S.d1 != 5) return EQF_E_UNSUPPORTED;
+      if (si > 0 && S.d1 <= X.seg[si - 1].d1) return EQF_E_UNSUPPORTED;  // one segment per input degree, in increasing order
+      nst[S.d1 >> 1] = S.npath * (S.mul / 16);
       if (S.mul % 16 != 0 || (S.x_off & 3)) return EQF_E_UNSUPPORTED;
       if (S.g_off >= 0 && (S.g_off & 3)) return EQF_E_UNSUPPORTED;
       d1max = S.d1 > d1max ? S.d1 : d1max;
@@ -511,6 +528,7 @@ int plan_yfwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, const XGate*
       T.ms = mlen | 1;
       T.wave_bytes = 2 * T.xs_bytes + (A.has_w ? 3 * 2048 : 0) + ((32 * T.ms * 4 + 15) & ~15);
       T.nsteps = (int)steps;
+      T.nst[0] = nst[0], T.nst[1] = nst[1], T.nst[2] = nst[2];
       if (steps > Y_MAXSTEP) return EQF_E_UNSUPPORTED;
       const size_t need = (size_t)Y_TAB_BYTES + (size_t)2 * cn * npw * 1024 + (size_t)Y_WAVES * T.wave_bytes;
       if (need > 160 * 1024) return EQF_E_UNSUPPORTED;
