@@ -66,6 +66,8 @@ struct YType {
   int wave_bytes;  // LDS per wave: 2 x slots + 3 w slots + coupling block
   int nsteps;      // (segment, chunk, path) steps of the degree
   int nst[3];      // ... of the segment of input degree 2 l1 + 1 = 1, 3, 5 (the segments run in this order)
+  int nsb;         // slots of the weight-plane ring: 3 (planes requested two steps ahead) where LDS allows, else 2 (one step)
+  int tab_bytes;   // step table, rounded to 1 KB
 };
 struct YFwdArgs {
   XFwdArgs f;  // tensors, per-degree segment / path tables, gate (plan_fwd)
@@ -84,23 +86,25 @@ __device__ __forceinline__ void glds16(const void* sbase, const unsigned voff, c
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst)
                : "memory");
 }
+// a wave-uniform value that hipcc chose to compute with vector instructions (selects of loop counters), back in an SGPR: the
+// opaque copy keeps the readfirstlane from being folded away
+__device__ __forceinline__ unsigned force_sgpr(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return __builtin_amdgcn_readfirstlane(v);
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
-// at most n DMA instructions of a loader wave still in flight (n even, <= 14: two w pieces + up to 2 (5 + 1) x pieces)
+// at most n DMA instructions of a loader wave still in flight (two w pieces + up to 2 (5 + 1) x pieces + up to 5 weight pieces)
 __device__ __forceinline__ void wait_vmcnt(const int n) {
-  switch (n >> 1) {
-    case 0: wait_vm<0>(); break;
-    case 1: wait_vm<2>(); break;
-    case 2: wait_vm<4>(); break;
-    case 3: wait_vm<6>(); break;
-    case 4: wait_vm<8>(); break;
-    case 5: wait_vm<10>(); break;
-    case 6: wait_vm<12>(); break;
-    case 7: wait_vm<14>(); break;
+#define Y_W(k) case k: wait_vm<k>(); break;
+  switch (n) {
+    Y_W(0) Y_W(1) Y_W(2) Y_W(3) Y_W(4) Y_W(5) Y_W(6) Y_W(7) Y_W(8) Y_W(9) Y_W(10) Y_W(11) Y_W(12) Y_W(13) Y_W(14) Y_W(15)
+    Y_W(16) Y_W(17) Y_W(18) Y_W(19) Y_W(20) Y_W(21) Y_W(22) Y_W(23) Y_W(24)
     default: wait_vm<0>(); break;
   }
+#undef Y_W
 }
 
 // One step of an item = (input segment, 16-channel chunk, path).  The table of an item's steps is built once per workgroup in
@@ -136,7 +140,7 @@ __device__ __forceinline__ YStep y_entry(const float* tab, const int s) {
 }
 
 // LDS map of a workgroup, bytes from the start of the dynamic segment:
-//   [step table][B slot 0][B slot 1] then per compute wave [x 0][x 1][w 0][w 1][w 2][M]
+//   [step table][B slots: 2 or 3] then per compute wave [x 0][x 1][w 0][w 1][w 2][M]
 struct YMap {
   unsigned lds0, bs_off, bs_bytes, wv_off, wave_bytes, xs_bytes, ws_rel, mb_rel;
 };
@@ -144,8 +148,8 @@ template <int NPW>
 __device__ __forceinline__ YMap y_map(const YFwdArgs& g, const YType& T) {
   YMap m;
   m.lds0 = (unsigned)(size_t)(lds_float*)sy_lds;
-  m.bs_off = Y_TAB_BYTES, m.bs_bytes = (unsigned)T.ct * NPW * 1024;
-  m.wv_off = m.bs_off + 2 * m.bs_bytes, m.wave_bytes = T.wave_bytes, m.xs_bytes = T.xs_bytes;
+  m.bs_off = T.tab_bytes, m.bs_bytes = (unsigned)T.ct * NPW * 1024;
+  m.wv_off = m.bs_off + T.nsb * m.bs_bytes, m.wave_bytes = T.wave_bytes, m.xs_bytes = T.xs_bytes;
   m.ws_rel = 2 * T.xs_bytes, m.mb_rel = m.ws_rel + (g.has_w ? 3 * 2048 : 0);
   return m;
 }
@@ -199,8 +203,17 @@ __device__ __forceinline__ void yf_loader(const YFwdArgs& g, const YType& T, con
   const int nsteps = T.nsteps, E = f.E;
   const YMap m = y_map<NPW>(g, T);
   const bool has_w = g.has_w != 0, gate_on = f.gate.on != 0;
-  const int e = min((grp * Y_WAVES + k) * 32 + r, E - 1);
-  const unsigned xoff = ((unsigned)e * f.x_ld + 8 * hi) * 4, woff = ((unsigned)e * f.w_ld + 8 * hi) * 4, boff = lane * 16;  // bytes
+  // x / w rows of a chunk (32 edges x 64 bytes per component) move as two DMAs of 16 rows x 64 bytes -- lane = (row, 16-byte
+  // piece), 16 half lines per instruction; the first version fetched the A-fragment shape directly (lane = (edge, k half): 32
+  // rows x 32 bytes, 32 lines per instruction) and the four loaders of a CU spent 1 250 - 2 000 cycles per step ISSUING them
+  // behind one another (profiles/r06/r06_k_*).  The LDS image is row-major [row][4 pieces] with the piece index XOR (row / 4)
+  // % 4, applied here on the source side (the DMA writes lane-linear) and again where the compute wave reads its fragment.
+  const int prow = lane >> 2, ppiece = (lane & 3) ^ ((lane >> 4) & 3);
+  const int e_lo = min((grp * Y_WAVES + k) * 32 + prow, E - 1), e_hi = min((grp * Y_WAVES + k) * 32 + prow + 16, E - 1);
+  const unsigned xoff0 = ((unsigned)e_lo * f.x_ld + 4 * ppiece) * 4, xoff1 = ((unsigned)e_hi * f.x_ld + 4 * ppiece) * 4;  // bytes
+  const unsigned woff0 = ((unsigned)e_lo * f.w_ld + 4 * ppiece) * 4, woff1 = ((unsigned)e_hi * f.w_ld + 4 * ppiece) * 4;
+  const unsigned boff = lane * 16;
+  (void)r, (void)hi;
   const char* const xg = reinterpret_cast<const char*>(f.x);
   const char* const wg = reinterpret_cast<const char*>(f.w);
   const char* const pf = reinterpret_cast<const char*>(f.packed + D.pf + (size_t)T.ct0 * NPW * 512);
@@ -210,7 +223,7 @@ __device__ __forceinline__ void yf_loader(const YFwdArgs& g, const YType& T, con
 
   auto issue_b = [&](const YStep& st, const int slot) __attribute__((always_inline)) {
     const char* const src = pf + (size_t)st.kt * kt_bytes;
-    const unsigned dst = m.lds0 + m.bs_off + slot * m.bs_bytes;
+    const unsigned dst = force_sgpr(m.lds0 + m.bs_off + slot * m.bs_bytes);
     for (int j = k; j < npiece; j += Y_WAVES) glds16(src + j * 1024, boff, dst + j * 1024);
   };
   auto issue_x = [&](const YStep& st) __attribute__((always_inline)) -> int {
@@ -222,13 +235,13 @@ __device__ __forceinline__ void yf_loader(const YFwdArgs& g, const YType& T, con
       constexpr int D1 = decltype(tag)::value;
 #pragma unroll
       for (int i = 0; i < D1; ++i) {
-        glds16(xb + (size_t)(i * mul) * 4, xoff, dst + i * 2048);
-        glds16(xb + (size_t)(i * mul) * 4 + 16, xoff, dst + i * 2048 + 1024);
+        glds16(xb + (size_t)(i * mul) * 4, xoff0, dst + i * 2048);
+        glds16(xb + (size_t)(i * mul) * 4, xoff1, dst + i * 2048 + 1024);
       }
       if (gp) {
         const char* const gb = xg + (size_t)st.g_off * 4;
-        glds16(gb, xoff, dst + D1 * 2048);
-        glds16(gb + 16, xoff, dst + D1 * 2048 + 1024);
+        glds16(gb, xoff0, dst + D1 * 2048);
+        glds16(gb, xoff1, dst + D1 * 2048 + 1024);
       }
     };
     switch (d1) {
@@ -240,12 +253,15 @@ __device__ __forceinline__ void yf_loader(const YFwdArgs& g, const YType& T, con
   };
   auto issue_w = [&](const YStep& st, const int slot) __attribute__((always_inline)) {
     const char* const wb = wg + (size_t)st.w_off * 4;
-    const unsigned dst = my + m.ws_rel + slot * 2048;
-    glds16(wb, woff, dst);
-    glds16(wb + 16, woff, dst + 1024);
+    const unsigned dst = force_sgpr(my + m.ws_rel + slot * 2048);
+    glds16(wb, woff0, dst);
+    glds16(wb, woff1, dst + 1024);
   };
 
   YStep E1 = y_entry(sy_lds, min(1, nsteps - 1)), E2 = y_entry(sy_lds, min(2, nsteps - 1));
+  const int nsb = T.nsb;
+  const bool lead2 = nsb == 3;  // weight planes two steps ahead
+  const int nb = (npiece - k + Y_WAVES - 1) / Y_WAVES;  // this loader's pieces of a weight stage
   int n_tail = 0;  // DMA instructions issued after the ones the next step needs
   {
     const YStep E0 = y_entry(sy_lds, 0);
@@ -253,21 +269,30 @@ __device__ __forceinline__ void yf_loader(const YFwdArgs& g, const YType& T, con
     if (has_w) issue_w(E0, 0);
     issue_b(E0, 0);
     if (nsteps > 1) {
+      if (lead2) issue_b(E1, 1), n_tail += nb;
       if (E1.flags & 1) n_tail += issue_x(E1);
       if (has_w) issue_w(E1, 1), n_tail += 2;
     }
   }
   int s3 = 0;
+#if EQF_Y_TRACE
+  long long yt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long yt_last = clock64();
+#endif
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
     wait_vmcnt(n_tail);
+    YT_STAMP(1);  // operands landed
     __builtin_amdgcn_s_barrier();
+    YT_STAMP(2);  // barrier
     const int4* const tq = reinterpret_cast<const int4*>(sy_lds) + 2 * min(s + 3, nsteps - 1);
     const int4 ta = tq[0], tb = tq[1];
     n_tail = 0;
-    if (s + 1 < nsteps) {
-      issue_b(E1, (s + 1) & 1);
-      if ((E1.flags & 9) == 9 && s > 0) issue_x(E1);  // (step 1's x went out with the prologue)
+    if (s + 1 < nsteps && (E1.flags & 9) == 9 && s > 0) issue_x(E1);  // late x of step s + 1 (step 1's went out with the prologue)
+    if (lead2) {
+      if (s + 2 < nsteps) issue_b(E2, s3 == 0 ? 2 : s3 - 1), n_tail += nb;  // slot (s + 2) % 3
+    } else {
+      if (s + 1 < nsteps) issue_b(E1, (s + 1) & 1);
     }
     if (s + 2 < nsteps) {
       if ((E2.flags & 9) == 1) n_tail += issue_x(E2);
@@ -275,7 +300,12 @@ __device__ __forceinline__ void yf_loader(const YFwdArgs& g, const YType& T, con
     }
     s3 = s3 == 2 ? 0 : s3 + 1;
     E1 = E2, E2 = y_unpack(ta, tb);
+    YT_STAMP(3);  // DMAs issued
   }
+#if EQF_Y_TRACE
+  if (grp == 3 && k == 0 && lane == 0)
+    printf("ytrace loader d3 %d ct %d steps %d: wait %lld barrier %lld issue %lld\n", D.d3, T.ct, nsteps, yt[1], yt[2], yt[3]);
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------------- compute waves
@@ -334,8 +364,14 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[m3][ct][q] = 0.f;
 
+  // this lane's A-fragment pieces (channels 8 hi .. 8 hi + 3 and + 4 .. + 7 of edge r) in the row-major, XOR-swizzled image of a
+  // chunk component (see yf_loader): float offsets of the first piece and from the first to the second
+  const int swz = (r >> 2) & 3;
+  const int frag0 = (r >> 4) * 256 + ((r & 15) * 4 + ((2 * hi) ^ swz)) * 4;
+  const int fragd = (((2 * hi + 1) ^ swz) - ((2 * hi) ^ swz)) * 4;
   YStep E0 = y_entry(sy_lds, 0);
   YStep E1 = y_entry(sy_lds, min(1, nsteps - 1));
+  const bool lead2 = T.nsb == 3;
   int s = 0, s3 = 0;  // s3 = s % 3
   YT_STAMP(0);
 
@@ -357,11 +393,11 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
       const int4* const tq = reinterpret_cast<const int4*>(sy_lds) + 2 * min(s + 2, nsteps - 1);
       const int4 ta = tq[0], tb = tq[1];
       if (E0.flags & 1) {  // first step of a chunk: its x rows out of their slot
-        const float* const xs = sy_lds + ((wv + ((E0.flags >> 2) & 1) * m.xs_bytes) >> 2) + lane * 4;
+        const float* const xs = sy_lds + ((wv + ((E0.flags >> 2) & 1) * m.xs_bytes) >> 2) + frag0;
 #pragma unroll
         for (int i = 0; i < D1; ++i) {
           const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs + i * 512);
-          const f32x4 a1 = *reinterpret_cast<const f32x4*>(xs + i * 512 + 256);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(xs + i * 512 + fragd);
 #pragma unroll
           for (int j = 0; j < 4; ++j) xf[i][j] = a0[j], xf[i][4 + j] = a1[j];
         }
@@ -371,7 +407,7 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
             for (int j = 0; j < 8; ++j) xf[0][j] = c_silu * xf[0][j] * xg_sigmoid(xf[0][j]);
           } else if (E0.g_off >= 0) {
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(xs + D1 * 512);
-            const f32x4 g1 = *reinterpret_cast<const f32x4*>(xs + D1 * 512 + 256);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(xs + D1 * 512 + fragd);
             float sg[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) sg[j] = c_sig * xg_sigmoid(g0[j]), sg[4 + j] = c_sig * xg_sigmoid(g1[j]);
@@ -385,9 +421,9 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
       YT_STAMP(3);  // x rows out of their slot
       float wf[8];
       if (has_w) {
-        const float* const ws = sy_lds + ((wv + m.ws_rel + s3 * 2048) >> 2) + lane * 4;
+        const float* const ws = sy_lds + ((wv + m.ws_rel + s3 * 2048) >> 2) + frag0;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(ws);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ws + 256);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ws + fragd);
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = valid ? a0[j] : 0.f, wf[4 + j] = valid ? a1[j] : 0.f;
       } else {
@@ -399,7 +435,8 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
       float mm[D1 * D3];
 #pragma unroll
       for (int k = 0; k < D1 * D3; ++k) mm[k] = mp[k];
-      const __bf16* const bs = reinterpret_cast<const __bf16*>(sy_lds) + ((m.bs_off + (s & 1) * m.bs_bytes) >> 1) + lane * 8;
+      const __bf16* const bs =
+          reinterpret_cast<const __bf16*>(sy_lds) + ((m.bs_off + (lead2 ? s3 : (s & 1)) * m.bs_bytes) >> 1) + lane * 8;
 #pragma unroll
       for (int m3 = 0; m3 < D3; ++m3) {
         float a[8];
@@ -434,26 +471,41 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
   // (two waves per SIMD -- a loader beside a compute wave -- so the register budget is 256 and hipcc keeps the accumulators in
   // VGPRs: no accumulator-file copies.  With 512 registers it copied all of them to VGPRs at the end of every iteration.)
   YT_STAMP(5);  // accumulators retired
-  // epilogue: accumulator register q of lane (r, hi) = row (edge) (q & 3) + 8 (q >> 2) + 4 hi, column r of the tile
+  // epilogue: accumulator register q of lane (r, hi) = row (edge) (q & 3) + 8 (q >> 2) + 4 hi, column r of the tile.  The tile goes
+  // through a wave-private LDS image (the wave's x slots are free: the loader's last DMA landed before the last barrier) and
+  // leaves as 16-byte stores of whole 128-byte lines, 8 rows per instruction -- 4 store instructions per 32 x 32 tile instead of 16
+  // (the 4-byte stores were 11-15 k of the 60 k cycles of a degree-0 item: profiles/r06/r06_i_*)
+  {
+    float* const Tt = sy_lds + (wv >> 2);  // two tile images of 32 x XT_LD floats, alternating
+    const int c4 = lane & 7, rr = lane >> 3;
+    int par = 0;
 #pragma unroll
-  for (int ct = 0; ct < CTM; ++ct) {
-    if (ct >= CT) continue;
-    const int c0 = (ct0 + ct) * 32;  // first column of the tile in the concatenated [main | second] output
-    const bool main = c0 < D.N1;     // scalar: N1 % 32 == 0 (a lane-dependent test turns ld into a per-lane LOAD from the kernarg
-                                     // segment and every store of the tile into store -> s_waitcnt vmcnt(0) -> store)
-    float bv = 0.f;
-    if (D3 == 1) bv = main ? (f.bias ? f.bias[c0 + r] : 0.f) : (f.bias2 ? f.bias2[c0 + r - D.N1] : 0.f);
-    asm volatile("" : "+v"(bv));  // the bias has ARRIVED here: otherwise every masked store below carries its own s_waitcnt vmcnt(0),
-                                  // which also waits for the store before it
-    float* const base = main ? f.o1 + D.out1_off + c0 : f.o2 + (c0 - D.N1);  // uniform
-    const unsigned ld = main ? f.ld1 : f.ld2;
+    for (int ct = 0; ct < CTM; ++ct) {
+      if (ct >= CT) continue;
+      const int c0 = (ct0 + ct) * 32;  // first column of the tile in the concatenated [main | second] output
+      const bool main = c0 < D.N1;     // scalar: N1 % 32 == 0
+      float bv = 0.f;
+      if (D3 == 1) bv = main ? (f.bias ? f.bias[c0 + r] : 0.f) : (f.bias2 ? f.bias2[c0 + r - D.N1] : 0.f);
+      asm volatile("" : "+v"(bv));  // (the bias has arrived: no wait inside the masked stores below)
+      float* const base = main ? f.o1 + D.out1_off + c0 : f.o2 + (c0 - D.N1);  // uniform
+      const unsigned ld = main ? f.ld1 : f.ld2;
 #pragma unroll
-    for (int m3 = 0; m3 < D3; ++m3)
+      for (int m3 = 0; m3 < D3; ++m3) {
+        float* const Tq = Tt + par * XT_FLOATS;
+        par ^= 1;
+        wave_lds_order();  // (the reads of this image's previous use are issued)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * hi;
-        if (e0 + row < E) base[(unsigned)(e0 + row) * ld + (unsigned)(m3 * D.N1 + r)] = acc[m3][ct][q] + bv;
+        for (int q = 0; q < 16; ++q) Tq[((q & 3) + 8 * (q >> 2) + 4 * hi) * XT_LD + r] = acc[m3][ct][q] + bv;
+        wave_lds_order();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = rr + 8 * it;
+          const f32x4 u = *reinterpret_cast<const f32x4*>(Tq + (row * XT_LD + 4 * c4));
+          if (e0 + row < E)
+            *reinterpret_cast<f32x4*>(base + ((unsigned)(e0 + row) * ld + (unsigned)(m3 * D.N1 + 4 * c4))) = u;
+        }
       }
+    }
   }
 #if EQF_Y_TRACE
   YT_STAMP(6);  // stores issued
@@ -530,7 +582,12 @@ int plan_yfwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, const XGate*
       T.nsteps = (int)steps;
       T.nst[0] = nst[0], T.nst[1] = nst[1], T.nst[2] = nst[2];
       if (steps > Y_MAXSTEP) return EQF_E_UNSUPPORTED;
-      const size_t need = (size_t)Y_TAB_BYTES + (size_t)2 * cn * npw * 1024 + (size_t)Y_WAVES * T.wave_bytes;
+      if (2 * T.xs_bytes < 2 * XT_FLOATS * 4) return EQF_E_UNSUPPORTED;  // (the epilogue's two tile images live in the x slots)
+      if ((C.ld1 | C.ld2) & 3) return EQF_E_UNSUPPORTED;                 // 16-byte stores
+      T.tab_bytes = (int)((steps * sizeof(YStep) + 1023) & ~(size_t)1023);
+      T.nsb = 3;
+      size_t need = (size_t)T.tab_bytes + (size_t)T.nsb * cn * npw * 1024 + (size_t)Y_WAVES * T.wave_bytes;
+      if (need > 160 * 1024) T.nsb = 2, need -= (size_t)cn * npw * 1024;
       if (need > 160 * 1024) return EQF_E_UNSUPPORTED;
       ldsmax = need > ldsmax ? need : ldsmax;
       cost[nt] = steps * (600 + 200 * X.d3 + 160 * X.d3 * cn);
