@@ -31,17 +31,22 @@ struct Planes<2> {
 };
 inline int mode_npw(int mode) { return mode == 1 ? 1 : 3; }
 
-// x = p[0] + p[1] + ... (+ residual below 2^-(8 NP) |x|): each plane is the bf16 rounding of what is left
+// x = p[0] + p[1] + ... (+ residual below 2^-(8 NP) |x|): each plane is the bf16 rounding of what is left.  The conversions go
+// in PAIRS (v_cvt_pk_bf16_f32 takes two values; written per element hipcc converted every value alone and packed the planes
+// with further conversions): 3 instead of 4 vector instructions per value and two planes, the same roundings bit for bit
+// (round 6; the activation splits are the largest VALU item of the two gradient kernels)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 template <int NP>
 __device__ __forceinline__ void split_planes(const float (&v)[8], bf16x8 (&p)[NP]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float r = v[j];
+  for (int jp = 0; jp < 4; ++jp) {
+    float r0 = v[2 * jp], r1 = v[2 * jp + 1];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const __bf16 h = (__bf16)r;
-      p[q][j] = h;
-      if (q + 1 < NP) r = r - (float)h;
+      const bf16x2 h = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
+      p[q][2 * jp] = h[0], p[q][2 * jp + 1] = h[1];
+      if (q + 1 < NP) r0 -= (float)h[0], r1 -= (float)h[1];
     }
   }
 }

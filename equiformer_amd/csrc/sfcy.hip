@@ -5,28 +5,35 @@
 //
 // [ref: SeparableFCTP.forward, nets/graph_attention_transformer.py:234-248]
 //
-// Why a second kernel (sfcx.hip's forward stays as the bit-level cross-check and serves small graphs / degree-3 models):
-// the one-wave items of sfcx_fwd each wait 1.0-1.4 us per step for operands they requested when they needed them, two
-// resident waves per SIMD cover neither, and 9 of the 13 wave-loads of a step are weight fragments that every 32-edge tile
-// re-reads through the CU's one address unit (profiles/r03/r03_s_what_bounds_the_forward.md; round 6: a better launch order
-// alone gave the operator without per-edge weights 25 %, a touch-prefetch of w made the other one slower -- the address unit,
-// not HBM latency, is what the steps queue on).  Here:
+// Why a second kernel (sfcx.hip's forward stays as the bit-level cross-check and serves small graphs / degree-3 models): the
+// one-wave items of sfcx_fwd each wait 1.0-1.4 us per step for operands they requested when they needed them, two resident
+// waves per SIMD cover neither, and 9 of the 13 wave-loads of a step are weight fragments that every 32-edge tile re-reads
+// through the CU's one address unit (profiles/r03/r03_s_what_bounds_the_forward.md).  Here (E = 25 354, split mode: 126 us
+// against 155 us for sep_act, 84 / 96 for sep_value, 100 / 115 with the gate folded in; results bit-identical; how it got there,
+// step by step with cycle traces: profiles/r06/r06_c ... r06_m):
 //
-//   * workgroup = 4 waves = 4 consecutive 32-edge tiles, all running the same item (output degree, column group) in step;
-//     the bf16 weight planes of a step (CT x NPW KB, one contiguous block of the packed buffer) are fetched ONCE per
-//     workgroup into a two-slot LDS ring by LDS-DMA (global_load_lds_dwordx4, 1 KB per instruction, no registers) and read by
-//     all four waves with ds_read_b128: a quarter of the weight traffic through the address unit, none of it in registers;
-//   * x and w of a wave's tile arrive by LDS-DMA as well, in the wave's private ring slots, one chunk / two steps ahead: a
-//     step never waits for an operand it has not requested at least a step earlier.  The only waits in the loop are counted
-//     s_waitcnt vmcnt(N) (the DMAs are inline asm: hipcc neither counts nor drains them) and one raw s_barrier per step;
-//   * column groups of 6 tiles on the scalar degree (registers: one wave per SIMD, 512 per lane): the degree-0 DTP output is
-//     generated twice per tile instead of four times.
-//
-// A step = (input segment, 16-channel chunk, path).  Order of the DMA queue of a wave, per iteration s (after the barrier):
-//   [its share of B(s+1)] [x of the next chunk, if step s opens a chunk] [w(s+2)]
-// and the wait that opens iteration s+1 leaves outstanding exactly what is not needed yet: w(s+2), and the x chunk unless
-// step s+1 opens it.  Ring slots: B 2 (slot of step s-1 is free once every wave passed barrier s), x 2, w 3, all wave-
-// private except B.
+//   * workgroup = 8 waves on 4 consecutive 32-edge tiles, all running the same item (output degree, column group) in step:
+//     COMPUTE wave t (0..3) owns tile t, LOADER wave 4 + t sits beside it on the same SIMD and issues every memory request
+//     of the tile -- the compute waves have no vector-memory instruction in their loop;
+//   * every operand arrives in LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, no registers, scalar base +
+//     per-lane offset): the bf16 weight planes of a step (CT x NPW KB, one contiguous block of the packed buffer) ONCE per
+//     workgroup into a ring of three slots (two where LDS is short), read by all four compute waves with ds_read_b128 -- a
+//     quarter of the weight traffic through the address unit; x and w of a tile as 16 rows x 64 bytes per instruction into
+//     the wave's private slots (x 2 chunks, w 3 pieces), row-major with an XOR swizzle that makes the fragment reads
+//     conflict free;
+//   * a step = (input segment, 16-channel chunk, path); its parameters come from a table the workgroup builds in LDS (one
+//     broadcast ds_read per step instead of ~30 dependent scalar loads from the kernarg tables);
+//   * one raw s_barrier per step is the only synchronisation: a loader waits (counted s_waitcnt vmcnt(N): the DMAs are
+//     inline asm, hipcc neither counts nor drains them) until what the NEXT step needs has landed, everybody meets, the
+//     loader requests what the step after next needs -- weight planes and w two steps ahead, x one or two;
+//   * the steps of an item run as one loop per input degree with a branch-free body (generation, split, matrix instructions of
+//     all 2 l3 + 1 components in one basic block): hipcc interleaves the vector work of component m3 + 1 with the matrix
+//     instructions of m3;
+//   * column groups of 6 tiles on the scalar degree: the degree-0 DTP output is generated twice per tile instead of four times;
+//   * output tiles leave through a wave-private LDS image as 16-byte stores of whole lines.
+// What bounds it now (r06_k / r06_l traces): a loader spends ~950 cycles per step issuing ~5 DMAs (the CU's address unit takes
+// ~43 cycles per 1 KB DMA and serves four loaders), then waits as long again for the previous step's to land, against 1 400
+// cycles of arithmetic per step -- deeper rings need LDS that the x slots (2 x 10 KB per tile) do not leave.
 #include "sfcx_common.h"
 
 extern __shared__ __attribute__((aligned(16))) float sy_lds[];
@@ -34,12 +41,6 @@ extern __shared__ __attribute__((aligned(16))) float sy_lds[];
 namespace {
 using namespace sfc;
 
-// development ablations (variant builds only: tools/bench_sfcy.py, profiles/r06): bit 0 no matrix instructions, bit 1 no
-// generation / split (constant A planes), bit 2 coupling block staged once per item only, bit 3 no stores, bit 4 no x / w DMA
-// after the prologue, bit 5 no B DMA after the prologue
-#ifndef EQF_Y_ABLATE
-#define EQF_Y_ABLATE 0
-#endif
 // development: -DEQF_Y_TRACE=1 prints the cycles one wave of the first workgroup of every item type spends per phase
 #ifndef EQF_Y_TRACE
 #define EQF_Y_TRACE 0
@@ -309,24 +310,6 @@ __device__ __forceinline__ void yf_loader(const YFwdArgs& g, const YType& T, con
 }
 
 // -------------------------------------------------------------------------------------------------------- compute waves
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// split_planes of sfcx_common.h with the conversions in PAIRS (v_cvt_pk_bf16_f32 takes two values): 24 instead of 32 vector
-// instructions per eight values and two planes; the same roundings, bit for bit
-template <int NP>
-__device__ __forceinline__ void split_planes_pk(const float (&v)[8], bf16x8 (&p)[NP]) {
-#pragma unroll
-  for (int jp = 0; jp < 4; ++jp) {
-    float r0 = v[2 * jp], r1 = v[2 * jp + 1];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const bf16x2 h = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
-      p[q][2 * jp] = h[0], p[q][2 * jp + 1] = h[1];
-      if (q + 1 < NP) r0 -= (float)h[0], r1 -= (float)h[1];
-    }
-  }
-}
-
 // The steps of an item run segment by segment, and the input degree of a segment only shapes the generation of the A values:
 // one loop per input degree (2 l1 + 1 = 1, 3, 5, in the order the planner guarantees), each with a branch-free step body --
 // generation, split and matrix instructions of all 2 l3 + 1 components in ONE basic block, so that hipcc's scheduler can put
@@ -449,7 +432,7 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] *= wf[j];
         bf16x8 pa[NPA];
-        split_planes_pk<NPA>(a, pa);
+        split_planes<NPA>(a, pa);
 #pragma unroll
         for (int ct = 0; ct < CTM; ++ct) {
           const int cc = ct < CT ? ct : CT - 1;  // (tiles past CT re-read the last one; their accumulators are never stored)
@@ -518,7 +501,8 @@ __device__ __forceinline__ void yf_compute(const YFwdArgs& g, const YType& T, co
 template <int MODE>
 __global__ __launch_bounds__(128 * Y_WAVES, 2) void sfcy_fwd_kernel(const YFwdArgs g_byval) {
   KERNARG_IN_PLACE(YFwdArgs);
-  // item-major launch order, heaviest item type first (the host sorts the types): grp fastest
+  // item-major launch order, heaviest item type first (the host sorts the types): grp fastest.  (Grouping the types of a tile
+  // group on one XCD, so that they meet their x rows in its L2, measured 3 % slower: the short items no longer fill the tail.)
   const int y = blockIdx.x / g.ngrp, grp = blockIdx.x - y * g.ngrp;
   const YType& T = g.type[y];
   y_build_table(g.f.deg[T.deg], T.nsteps);
