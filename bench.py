@@ -61,6 +61,9 @@ def parse():
                          "out of idle clocks ramps for a second or two -- profiles/r05/r05_drv_bench_default_cold_box.json "
                          "has a headline region at 11 138 molecules/s followed, 3 s later in the same process, by a bf16 "
                          "sub-record at 13 749.  0 disables; the timed region is still exactly K steps after W warm-up steps")
+    ap.add_argument("--no-hip-graph", dest="hip_graph", action="store_false",
+                    help="launch the QM9 step eagerly (~280 launches per step) instead of replaying its HIP graph "
+                         "(equiformer_amd/capture.py; one GPU only: data-parallel steps are always eager)")
     ap.add_argument("--diag-static-graph", action="store_true",
                     help="DIAGNOSTIC, not a valid measurement: build the radius graph once outside the step (no host "
                          "synchronisation inside the step) -- shows how much of the step is the graph's sync bubble")
@@ -170,9 +173,12 @@ def build_workload(args, dev, rank, world):
         g = EdgeGraph.from_radius(d["pos"], d["batch"], 5.0)
         static_graph = g if getattr(args, "diag_static_graph", False) else None
 
-        def fwd_loss():
-            pred = model(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"], graph=static_graph)
+        def fwd_loss(graph=None):
+            pred = model(f_in=None, pos=d["pos"], batch=d["batch"], node_atom=d["z"], graph=graph or static_graph)
             return (pred.squeeze() - d["y"]).abs().mean()  # L1Loss (main_qm9.py:188-189)
+
+        def build_graph(into):  # the radius graph of the step's batch, rebuilt EVERY step (outside the captured part)
+            return EdgeGraph.from_radius(d["pos"], d["batch"], 5.0, num_graphs=args.batch, into=into)
         units = args.batch
         text = ("QM9 %s train step (radius graph + fwd + L1 + bwd + AdamW), %d molecules/GPU x %d atoms, r=5.0, "
                 "num_basis=128, alpha_drop=0.2" % (W["model"], args.batch, args.atoms))
@@ -212,7 +218,15 @@ def build_workload(args, dev, rank, world):
     reducer.broadcast_parameters()
     opt = make_optimizer(model, reducer=reducer if world > 1 else None, **opt_kw)
 
-    def step():
+    captured = None
+    if (args.workload == "qm9" and world == 1 and getattr(args, "hip_graph", True)
+            and not getattr(args, "diag_static_graph", False)):
+        # one GPU: forward + loss + backward + AdamW replayed as ONE HIP graph per step (equiformer_amd/capture.py); the radius
+        # graph is still rebuilt from the positions every step, outside the graph (its edge count is read back on the host)
+        from equiformer_amd.capture import CapturedTrainStep
+        captured = CapturedTrainStep(opt, fwd_loss)
+
+    def step_eager():
         opt.zero_grad(set_to_none=True)
         loss = fwd_loss()
         loss.backward()
@@ -220,7 +234,11 @@ def build_workload(args, dev, rank, world):
             reducer.reduce()
         opt.step()
         return loss
-    return dict(step=step, units=units, nodes=g.N, edges=g.E, text=text, model_name=W["model"])
+
+    def step_graph():
+        return captured.step(build_graph)
+    return dict(step=step_graph if captured is not None else step_eager, step_eager=step_eager, units=units, nodes=g.N,
+                edges=g.E, text=text, model_name=W["model"], captured=captured)
 
 
 def cpu_baseline_other(args):
@@ -392,26 +410,30 @@ def measure(args, dev, rank, world, workload, mode, steps, warmup, regions=("sfc
                 break
     for _ in range(warmup):
         step()
-    regions = list(regions)
-    if regions and regions[0] == "auto":
+    regions = [r for r in regions if r != "graph" or wl["captured"] is not None]
+    step_eager = wl["step_eager"]
+    if "auto" in regions:
         # one more untimed step with events on the SeparableFCTP kernels picks the dominant one; the timed region then carries
         # events on THAT kernel only (every event pair is a dependency between consecutive launches: events on all 39
         # SeparableFCTP launches of a QM9 step cost ~2 % of the step, `spread` [0] vs [2] of round 4)
         lib.prof_enable("sfc")  # sfcx_* (split / bf16 modes) and sfc_* (fp32 mode)
-        step()
+        step_eager()
         torch.cuda.synchronize()
         first = lib.prof_report()
         lib.prof_enable(None)
-        regions[0] = max(first, key=lambda k: first[k]["total_ms"]) if first else ""
+        regions[regions.index("auto")] = max(first, key=lambda k: first[k]["total_ms"]) if first else ""
     out = []
     loss = None
     for flt in regions:
-        lib.prof_enable(flt)
+        # "graph": the step replayed as one HIP graph (no per-launch events possible: the library's entry points are not called);
+        # every other region launches eagerly, with HIP events on the kernels whose name contains `flt` (None: no events)
+        run = step if flt == "graph" else step_eager
+        lib.prof_enable(None if flt == "graph" else flt)
         ops.deferred_weight_gradient_stats(reset=True)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            loss = step()
+            loss = run()
         barrier()
         dt = time.perf_counter() - t0
         prof = lib.prof_report()
@@ -435,13 +457,18 @@ def sub_record(args, dev, workload, mode, steps=10, warmup=3):
         # HIP events on the dominant SeparableFCTP kernel only, as in the headline region: the MD17 steps are launch-bound, and an
         # event pair around each of their ~500 matrix-core launches cost the round-4 sub-records 10-15 % (standalone 462 frames/s
         # vs 399 in the sub-record, profiles/r05)
-        wl, regs, loss = measure(a2, dev, 0, 1, workload, mode, steps, warmup, regions=("auto",))
-        dt, prof, _ = regs[0]
+        # (QM9 records: the value from the HIP-graph region, the dominant kernel from the eager region behind it, as in the headline)
+        wl, regs, loss = measure(a2, dev, 0, 1, workload, mode, steps, warmup, regions=("graph", "auto"))
+        dt = regs[0][0]
+        dt_rf, prof, _ = regs[-1]
         rec = {"workload": workload, "matrix_mode": mode, "dtype": "bf16" if mode == "bf16" else "f32",
                "model": wl["model_name"], "value": wl["units"] * steps / dt, "unit": WORKLOADS[workload]["unit"],
                "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "units_per_step": wl["units"],
-               "nodes": wl["nodes"], "edges": wl["edges"], "final_loss": loss, "what": wl["text"]}
-        rf = roofline_of(prof, dt, mode, with_pmc=False)
+               "nodes": wl["nodes"], "edges": wl["edges"], "final_loss": loss, "what": wl["text"],
+               "hip_graph": regs[0][2] == "graph"}
+        if len(regs) > 1:
+            rec["ms_per_step_eager"] = 1e3 * dt_rf / steps
+        rf = roofline_of(prof, dt_rf, mode, with_pmc=False)
         if rf:
             rec["dominant"] = {k: rf[k] for k in ("kernel", "launches", "avg_launch_ms", "achieved", "peak", "frac", "unit",
                                                   "share_of_step") if k in rf}
@@ -502,10 +529,18 @@ def main():
     # dominant kernel only (picked among the SeparableFCTP kernels by one profiled, untimed step after the warm-up; `--dominant`
     # overrides).  Regions 2 and 3 repeat the same K steps for the
     # run-to-run spread: 2 with events on every matrix-core kernel (figures of the other kernels), 3 with no events at all.
+    # One GPU, QM9: region 1 replays the step as ONE HIP graph (equiformer_amd/capture.py) -- that is `value`; the per-kernel
+    # figures of `roofline` then come from region 2, the same K steps launched eagerly with events on the dominant kernel (a
+    # replayed launch cannot carry host-side events; a kernel's duration does not depend on how it was launched, and the
+    # rocprofv3 kernel trace of this command, profiles/r06, sees the replayed launches).
     first = args.dominant if args.dominant else "auto"
     regions = (first, "", None) if args.repeats >= 3 else ((first, "") if args.repeats == 2 else (first,))
+    regions = ("graph",) + regions  # (dropped by measure() where the step is not captured)
     wl, regs, loss = measure(args, dev, rank, world, args.workload, args.matrix_mode, args.steps, args.warmup, regions)
-    dt, prof, flt0 = regs[0]
+    graphed = regs[0][2] == "graph"
+    dt = regs[0][0]
+    irf = 1 if (graphed and len(regs) > 1) else 0  # the region whose events feed `roofline`
+    dt_rf, prof, flt0 = regs[irf]
     n_nodes, n_edges = wl["nodes"], wl["edges"]
 
     if rank == 0:
@@ -536,11 +571,20 @@ def main():
             },
         }
         vals = [wl["units"] * world * args.steps / d for d, _, _ in regs]
+        what = {"graph": "the step replayed as one HIP graph", "": "eager launches, events on every matrix-core launch",
+                None: "eager launches, no events"}
         out["spread"] = {"values": vals, "min": min(vals), "max": max(vals),
-                         "note": "the same %d steps timed %d times back to back in this process: [0] = `value` (HIP events on the "
-                                 "launches of `%s`), [1] events on every matrix-core launch, [2] no events" % (args.steps, len(vals), flt0)}
-        rf = roofline_of(prof, dt, args.matrix_mode)
-        allprof = regs[1][1] if len(regs) > 1 else prof
+                         "regions": [what.get(f, "eager launches, HIP events on the launches of `%s`" % f) for _, _, f in regs],
+                         "note": "the same %d steps timed %d times back to back in this process; [0] = `value`" % (args.steps, len(vals))}
+        out["config"]["hip_graph"] = bool(graphed)
+        if graphed and wl.get("captured") is not None:
+            out["config"]["hip_graph_replays"] = wl["captured"].replays
+            out["config"]["hip_graph_eager_steps"] = wl["captured"].eager_steps
+        rf = roofline_of(prof, dt_rf, args.matrix_mode)
+        if rf is not None and graphed:
+            rf["measured_in"] = ("region [%d] of `spread`: the same %d steps launched eagerly with HIP events on this kernel's launches "
+                                 "(%.3f ms/step there); `value` is region [0], where the step is one graph launch" % (irf, args.steps, 1e3 * dt_rf / args.steps))
+        allprof = regs[irf + 1][1] if len(regs) > irf + 1 else prof
         if rf is not None:
             out["roofline"] = rf
             # the other matrix-core kernels of the step, same accounting (second region; not part of the contract)
@@ -552,7 +596,7 @@ def main():
                 tf = r2["flops"] / r2["total_ms"] / 1e9
                 others.append({"kernel": n2, "launches": r2["launches"], "avg_launch_ms": r2["total_ms"] / r2["launches"],
                                "achieved": tf, "peak": pk, "frac": tf / pk,
-                               "share_of_step": r2["total_ms"] / (1e3 * regs[1][0] if len(regs) > 1 else 1e3 * dt)})
+                               "share_of_step": r2["total_ms"] / (1e3 * regs[irf + 1][0] if len(regs) > irf + 1 else 1e3 * dt_rf)})
             out["roofline"]["others"] = others[:8]
         # the two kernels BASELINE.json's north_star asks to be stated against the gfx950 peaks (not part of the contract
         # line): HBM GB/s of the per-destination softmax + scatter (algorithmic bytes 1 940 E + 1 920 N per call,

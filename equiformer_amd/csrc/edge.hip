@@ -347,7 +347,10 @@ constexpr int MAX_SLOTS = 4;  // up to 256 float4 groups (1024 channels) per hea
 
 __global__ void attn_fwd_kernel(const float* __restrict__ logit, const float* __restrict__ value,
                                 const int* __restrict__ row_ptr, float* __restrict__ alpha, float* __restrict__ out,
-                                const HeadTab T, float drop_p, unsigned long long seed) {
+                                const HeadTab T, float drop_p, unsigned long long seed0,
+    const unsigned long long* __restrict__ seed_off) {
+  // (the mask seed of a launch captured in a HIP graph: host part + a device word the caller advances between replays)
+  const unsigned long long seed = seed0 + (seed_off ? *seed_off : 0ull);
   const int n = blockIdx.x;
   const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int beg = row_ptr[n], end = row_ptr[n + 1];
@@ -389,7 +392,10 @@ __global__ void attn_fwd_kernel(const float* __restrict__ logit, const float* __
 // instead of one with 30 of 64 lanes working; the halves are folded with one shuffle at the end.
 __global__ void attn_fwd_half_kernel(const float* __restrict__ logit, const float* __restrict__ value,
                                      const int* __restrict__ row_ptr, float* __restrict__ alpha,
-                                     float* __restrict__ out, const HeadTab T, float drop_p, unsigned long long seed) {
+                                     float* __restrict__ out, const HeadTab T, float drop_p, unsigned long long seed0,
+    const unsigned long long* __restrict__ seed_off) {
+  // (the mask seed of a launch captured in a HIP graph: host part + a device word the caller advances between replays)
+  const unsigned long long seed = seed0 + (seed_off ? *seed_off : 0ull);
   const int n = blockIdx.x;
   const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int half = lane >> 5, gl = lane & 31;
@@ -443,7 +449,10 @@ __global__ void attn_fwd_half_kernel(const float* __restrict__ logit, const floa
 __global__ void attn_bwd_half_kernel(const float* __restrict__ alpha, const float* __restrict__ value,
                                      const int* __restrict__ row_ptr, const float* __restrict__ d_out,
                                      float* __restrict__ d_value, float* __restrict__ d_logit, const HeadTab T,
-                                     float drop_p, unsigned long long seed) {
+                                     float drop_p, unsigned long long seed0,
+    const unsigned long long* __restrict__ seed_off) {
+  // (the mask seed of a launch captured in a HIP graph: host part + a device word the caller advances between replays)
+  const unsigned long long seed = seed0 + (seed_off ? *seed_off : 0ull);
   const int n = blockIdx.x;
   const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int half = lane >> 5, gl = lane & 31;
@@ -495,7 +504,10 @@ __global__ void attn_bwd_half_kernel(const float* __restrict__ alpha, const floa
 __global__ void attn_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ value,
                                 const int* __restrict__ row_ptr, const float* __restrict__ d_out,
                                 float* __restrict__ d_value, float* __restrict__ d_logit, const HeadTab T, float drop_p,
-                                unsigned long long seed) {
+                                unsigned long long seed0,
+    const unsigned long long* __restrict__ seed_off) {
+  // (the mask seed of a launch captured in a HIP graph: host part + a device word the caller advances between replays)
+  const unsigned long long seed = seed0 + (seed_off ? *seed_off : 0ull);
   const int n = blockIdx.x;
   const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int beg = row_ptr[n], end = row_ptr[n + 1];
@@ -693,8 +705,9 @@ int eqf_alpha_bwd(const float* a, const float* alpha_dot, const float* d_logit, 
   return 0;
 }
 
-int eqf_attn_aggregate_fwd(const float* logit, const float* value, const int* row_ptr, float* alpha, float* out, int N,
-                           int H, const eqf_irreps* irreps, float drop_p, unsigned long long seed, void* stream) {
+static int attn_aggregate_fwd_impl(const float* logit, const float* value, const int* row_ptr, float* alpha, float* out, int N,
+                                   int H, const eqf_irreps* irreps, float drop_p, unsigned long long seed,
+                                   const unsigned long long* seed_off, void* stream) {
   if (!logit || !value || !row_ptr || !alpha || !out || !irreps || H < 1) return EQF_E_BADARG;
   int err;
   const HeadTab T = make_headtab(*irreps, H, &err);
@@ -705,18 +718,28 @@ int eqf_attn_aggregate_fwd(const float* logit, const float* value, const int* ro
   const int pid = eqf_prof_begin("attn_fwd", (hipStream_t)stream, 0.0, 0.0);
   if (T.G <= 32)
     hipLaunchKernelGGL(attn_fwd_half_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, logit, value, row_ptr, alpha,
-                       out, T, drop_p, seed);
+                       out, T, drop_p, seed, seed_off);
   else
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, logit, value, row_ptr, alpha, out,
-                       T, drop_p, seed);
+                       T, drop_p, seed, seed_off);
   eqf_prof_end(pid, (hipStream_t)stream);
   EQF_CHECK_LAUNCH();
   return 0;
 }
 
-int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* row_ptr, const float* d_out,
-                           float* d_value, float* d_logit, int N, int H, const eqf_irreps* irreps, float drop_p,
-                           unsigned long long seed, void* stream) {
+int eqf_attn_aggregate_fwd(const float* logit, const float* value, const int* row_ptr, float* alpha, float* out, int N,
+                           int H, const eqf_irreps* irreps, float drop_p, unsigned long long seed, void* stream) {
+  return attn_aggregate_fwd_impl(logit, value, row_ptr, alpha, out, N, H, irreps, drop_p, seed, nullptr, stream);
+}
+int eqf_attn_aggregate_fwd_dseed(const float* logit, const float* value, const int* row_ptr, float* alpha, float* out, int N,
+                                 int H, const eqf_irreps* irreps, float drop_p, unsigned long long seed,
+                                 const unsigned long long* seed_offset, void* stream) {
+  return attn_aggregate_fwd_impl(logit, value, row_ptr, alpha, out, N, H, irreps, drop_p, seed, seed_offset, stream);
+}
+
+static int attn_aggregate_bwd_impl(const float* alpha, const float* value, const int* row_ptr, const float* d_out,
+                                   float* d_value, float* d_logit, int N, int H, const eqf_irreps* irreps, float drop_p,
+                                   unsigned long long seed, const unsigned long long* seed_off, void* stream) {
   if (!alpha || !value || !row_ptr || !d_out || !d_value || !d_logit || !irreps || H < 1) return EQF_E_BADARG;
   int err;
   const HeadTab T = make_headtab(*irreps, H, &err);
@@ -725,13 +748,23 @@ int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* ro
   const int pid = eqf_prof_begin("attn_bwd", (hipStream_t)stream, 0.0, 0.0);
   if (T.G <= 32)
     hipLaunchKernelGGL(attn_bwd_half_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, alpha, value, row_ptr, d_out,
-                       d_value, d_logit, T, drop_p, seed);
+                       d_value, d_logit, T, drop_p, seed, seed_off);
   else
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(N), dim3(64 * H), 0, (hipStream_t)stream, alpha, value, row_ptr, d_out,
-                       d_value, d_logit, T, drop_p, seed);
+                       d_value, d_logit, T, drop_p, seed, seed_off);
   eqf_prof_end(pid, (hipStream_t)stream);
   EQF_CHECK_LAUNCH();
   return 0;
+}
+int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* row_ptr, const float* d_out,
+                           float* d_value, float* d_logit, int N, int H, const eqf_irreps* irreps, float drop_p,
+                           unsigned long long seed, void* stream) {
+  return attn_aggregate_bwd_impl(alpha, value, row_ptr, d_out, d_value, d_logit, N, H, irreps, drop_p, seed, nullptr, stream);
+}
+int eqf_attn_aggregate_bwd_dseed(const float* alpha, const float* value, const int* row_ptr, const float* d_out,
+                                 float* d_value, float* d_logit, int N, int H, const eqf_irreps* irreps, float drop_p,
+                                 unsigned long long seed, const unsigned long long* seed_offset, void* stream) {
+  return attn_aggregate_bwd_impl(alpha, value, row_ptr, d_out, d_value, d_logit, N, H, irreps, drop_p, seed, seed_offset, stream);
 }
 
 }  // extern "C"

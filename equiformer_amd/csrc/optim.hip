@@ -35,6 +35,8 @@ struct AdamArgs {
   const float* sumsq;  // may be null (no clipping)
   long n;
   float lr, beta1, beta2, eps, bc1, bc2_sqrt, max_norm, ema_decay;
+  const float* hyper;  // may be null; else {lr, bc1, bc2_sqrt} are read from this device array (a launch captured in a HIP graph:
+                       // the by-value ones are frozen at capture)
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float wd, float* ema, const AdamArgs& a,
@@ -52,7 +54,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   if (ema) *ema = a.ema_decay * *ema + (1.f - a.ema_decay) * p;
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a_in) {
+  AdamArgs a = a_in;
+  if (a.hyper) a.lr = a.hyper[0], a.bc1 = a.hyper[1], a.bc2_sqrt = a.hyper[2];
   float clip = 1.f;
   if (a.sumsq) {  // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
     const float c = a.max_norm / (sqrtf(*a.sumsq) + 1e-6f);
@@ -94,16 +98,17 @@ int eqf_sumsq(const float* g, long n, float* out, void* stream) {
   return 0;
 }
 
-int eqf_adamw_step(float* p, const float* g, float* m, float* v, const float* wd, float* ema, const float* sumsq, long n,
-                   float lr, float beta1, float beta2, float eps, int step, float max_norm, float ema_decay,
-                   void* stream) {
-  if (!p || !g || !m || !v || !wd || n < 0 || step < 1) return EQF_E_BADARG;
+static int adamw_launch(float* p, const float* g, float* m, float* v, const float* wd, float* ema, const float* sumsq, long n,
+                        float lr, float beta1, float beta2, float eps, int step, const float* hyper, float max_norm,
+                        float ema_decay, void* stream) {
+  if (!p || !g || !m || !v || !wd || n < 0 || (!hyper && step < 1)) return EQF_E_BADARG;
   if (n == 0) return 0;
   AdamArgs a;
   a.p = p, a.g = g, a.m = m, a.v = v, a.wd = wd, a.ema = ema, a.sumsq = sumsq, a.n = n;
   a.lr = lr, a.beta1 = beta1, a.beta2 = beta2, a.eps = eps;
-  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.hyper = hyper;
+  a.bc1 = hyper ? 1.f : (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2_sqrt = hyper ? 1.f : (float)sqrt(1.0 - pow((double)beta2, (double)step));
   a.max_norm = max_norm, a.ema_decay = ema_decay;
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -111,6 +116,19 @@ int eqf_adamw_step(float* p, const float* g, float* m, float* v, const float* wd
   hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
   EQF_CHECK_LAUNCH();
   return 0;
+}
+
+int eqf_adamw_step(float* p, const float* g, float* m, float* v, const float* wd, float* ema, const float* sumsq, long n,
+                   float lr, float beta1, float beta2, float eps, int step, float max_norm, float ema_decay,
+                   void* stream) {
+  return adamw_launch(p, g, m, v, wd, ema, sumsq, n, lr, beta1, beta2, eps, step, nullptr, max_norm, ema_decay, stream);
+}
+
+int eqf_adamw_step_dev(float* p, const float* g, float* m, float* v, const float* wd, float* ema, const float* sumsq, long n,
+                       const float* hyper, float beta1, float beta2, float eps, float max_norm, float ema_decay,
+                       void* stream) {
+  if (!hyper) return EQF_E_BADARG;
+  return adamw_launch(p, g, m, v, wd, ema, sumsq, n, 0.f, beta1, beta2, eps, 0, hyper, max_norm, ema_decay, stream);
 }
 
 }  // extern "C"

@@ -39,15 +39,18 @@ CSR_MAX_NODES = 16384  # nodes per molecule the by-source kernel keeps cursors f
 class EdgeGraph:
     """N nodes, E directed edges sorted by dst.  All index tensors are int32 on the GPU."""
 
-    def __init__(self, N, src, dst, row_ptr, batch=None, num_graphs=None, mol_ptr=None, max_mol_nodes=None):
+    def __init__(self, N, src, dst, row_ptr, batch=None, num_graphs=None, mol_ptr=None, max_mol_nodes=None, by_source_into=None):
         self.N = int(N)
         self.src, self.dst, self.row_ptr = src, dst, row_ptr
         self.E = int(src.shape[0])
         # by-source view: edges grouped by src (for gradients that flow back to the source node)
         if mol_ptr is not None and max_mol_nodes is not None and max_mol_nodes <= CSR_MAX_NODES and src.is_cuda:
             # radius graphs: molecule-blocked, no multi-edges -> one HIP launch instead of a device sort
-            self.src_perm = torch.empty(self.E, dtype=torch.int32, device=src.device)
-            self.src_ptr = torch.empty(self.N + 1, dtype=torch.int32, device=src.device)
+            if by_source_into is not None:  # (a captured step's static graph: the same buffers every step)
+                self.src_perm, self.src_ptr = by_source_into
+            else:
+                self.src_perm = torch.empty(self.E, dtype=torch.int32, device=src.device)
+                self.src_ptr = torch.empty(self.N + 1, dtype=torch.int32, device=src.device)
             call("eqf_csr_by_source", _P(src), _P(row_ptr), _P(mol_ptr), int(mol_ptr.shape[0]) - 1, int(max_mol_nodes),
                  _P(self.src_perm), _P(self.src_ptr), _stream())
         else:
@@ -67,8 +70,10 @@ class EdgeGraph:
         self.mol_ptr = _ptr_from_counts(torch.bincount(batch.to(torch.int64), minlength=self.num_graphs))
 
     @staticmethod
-    def from_radius(pos, batch, r, max_num_neighbors=1000, num_graphs=None):
-        """Radius graph per molecule (nodes of a molecule contiguous, `batch` ascending)."""
+    def from_radius(pos, batch, r, max_num_neighbors=1000, num_graphs=None, into=None):
+        """Radius graph per molecule (nodes of a molecule contiguous, `batch` ascending).  into: a graph of an earlier call; when
+        this call finds the same node and edge counts its index tensors are REWRITTEN in place and `into` is returned -- the
+        launches of a HIP-graph-captured step (equiformer_amd/capture.py) read those addresses."""
         if not pos.is_cuda:
             raise ops.HipOnlyError("radius graph construction runs on the GPU only")
         pos = pos.detach().to(torch.float32).contiguous()
@@ -86,11 +91,23 @@ class EdgeGraph:
         row_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         call("eqf_exclusive_scan_i32", _P(deg), N, _P(row_ptr), _P(stats), st)
         E, max_mol_nodes = stats.tolist()  # the one host sync of graph construction (the reference syncs here as well)
+        if (into is not None and into.N == N and into.E == E and into.num_graphs == int(num_graphs)
+                and into.src.device == dev and getattr(into, "_radius_static", False)):
+            into.row_ptr.copy_(row_ptr)
+            into.mol_ptr.copy_(mol_ptr)
+            if into.batch.data_ptr() != b32.data_ptr():
+                into.batch.copy_(b32)
+            call("eqf_radius_graph_fill", _P(pos), _P(into.mol_ptr), num_graphs, float(r), int(max_num_neighbors),
+                 _P(into.row_ptr), _P(into.src), _P(into.dst), st)
+            call("eqf_csr_by_source", _P(into.src), _P(into.row_ptr), _P(into.mol_ptr), int(num_graphs), int(max_mol_nodes),
+                 _P(into.src_perm), _P(into.src_ptr), st)
+            return into
         src = torch.empty(E, dtype=torch.int32, device=dev)
         dst = torch.empty(E, dtype=torch.int32, device=dev)
         call("eqf_radius_graph_fill", _P(pos), _P(mol_ptr), num_graphs, float(r), int(max_num_neighbors), _P(row_ptr),
              _P(src), _P(dst), st)
         g = EdgeGraph(N, src, dst, row_ptr, mol_ptr=mol_ptr, max_mol_nodes=max_mol_nodes)
+        g._radius_static = max_mol_nodes <= CSR_MAX_NODES  # (its by-source view came from eqf_csr_by_source: refillable in place)
         g.batch = b32
         g.num_graphs = int(num_graphs)
         g.mol_ptr = mol_ptr

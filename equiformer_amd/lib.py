@@ -60,6 +60,7 @@ SIGNATURES = {
     "eqf_radius_graph_pbc_fill": [c_fp, c_fp, c_fp, c_int, _f, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "eqf_sumsq": [c_fp, ctypes.c_long, c_fp, c_fp],
     "eqf_adamw_step": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_long, _f, _f, _f, _f, c_int, _f, _f, c_fp],
+    "eqf_adamw_step_dev": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_long, c_fp, _f, _f, _f, _f, _f, c_fp],
     "eqf_segment_ptr": [c_fp, c_int, c_int, c_fp, c_fp, c_fp],
     "eqf_exclusive_scan_i32": [c_fp, c_int, c_fp, c_fp, c_fp],
     "eqf_csr_by_source": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp],
@@ -130,6 +131,8 @@ SIGNATURES = {
     "eqf_alpha_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, _f, c_fp],
     "eqf_attn_aggregate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp],
     "eqf_attn_aggregate_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp],
+    "eqf_attn_aggregate_fwd_dseed": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp, c_fp],
+    "eqf_attn_aggregate_bwd_dseed": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _u64, c_fp, c_fp],
     "eqf_silu_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, _long, _f, c_fp],
     "eqf_gate_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _P_IRR, _f, _f, c_fp],
     "eqf_lnsilu_bwd2": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, _f, c_fp],

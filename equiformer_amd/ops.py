@@ -5,6 +5,7 @@ tensors must live on the GPU, otherwise `HipOnlyError` is raised.
 The operators are the closed primitive set of SURVEY.md Appendix B; `equiformer_amd.nets` composes them into the
 reference's module tree.
 """
+import contextlib
 import ctypes
 import os
 import weakref
@@ -2497,6 +2498,23 @@ def alpha_logits(a, alpha_dot, H, Kh, c):
     return _AlphaLogits.apply(a, alpha_dot, H, Kh, float(c))
 
 
+# Dropout under HIP-graph capture (equiformer_amd/capture.py): the by-value seed of a captured launch is frozen, so while a step
+# is being captured the attention kernels take seed + *offset with `offset` a device word the captured step advances between
+# replays (eqf_attn_aggregate_*_dseed).  None outside a capture.
+_seed_offset = [None]
+
+
+@contextlib.contextmanager
+def dropout_seed_offset(t):
+    """t: one-element int64 CUDA tensor (or None)."""
+    prev = _seed_offset[0]
+    _seed_offset[0] = t
+    try:
+        yield
+    finally:
+        _seed_offset[0] = prev
+
+
 class _AttnAggregate(Function):
     @staticmethod
     def forward(ctx, logit, value, graph, H, layout, drop_p, seed):
@@ -2505,10 +2523,16 @@ class _AttnAggregate(Function):
         N = graph.N
         alpha = torch.empty_like(logit)
         out = torch.empty((N, layout.dim), device=value.device, dtype=torch.float32)
-        call("eqf_attn_aggregate_fwd", _p(logit), _p(value), _p(graph.row_ptr), _p(alpha), _p(out), N, H, layout.c_ref,
-             drop_p, seed, _stream())
+        off = _seed_offset[0] if drop_p > 0.0 else None
+        if off is None:
+            call("eqf_attn_aggregate_fwd", _p(logit), _p(value), _p(graph.row_ptr), _p(alpha), _p(out), N, H, layout.c_ref,
+                 drop_p, seed, _stream())
+        else:
+            call("eqf_attn_aggregate_fwd_dseed", _p(logit), _p(value), _p(graph.row_ptr), _p(alpha), _p(out), N, H,
+                 layout.c_ref, drop_p, seed, _p(off), _stream())
         ctx.save_for_backward(alpha, value, logit)
         ctx.args = (graph, H, layout, drop_p, seed)
+        ctx.seed_off = off
         return out
 
     @staticmethod
@@ -2516,14 +2540,20 @@ class _AttnAggregate(Function):
         alpha, value, logit = ctx.saved_tensors
         graph, H, layout, drop_p, seed = ctx.args
         if torch.is_grad_enabled():  # create_graph (the dropout mask is replayed from the seed)
+            if ctx.seed_off is not None:
+                raise NotImplementedError("second-order backward of a captured step with attention dropout")
             dlogit, dvalue = _AttnAggregateBwd.apply(logit, value, dout, alpha, graph, H, layout, drop_p, seed)
             return dlogit, dvalue, None, None, None, None, None
         dout = _c(dout)
         _chk(dout)
         dvalue = torch.empty_like(value)
         dlogit = torch.empty_like(alpha)
-        call("eqf_attn_aggregate_bwd", _p(alpha), _p(value), _p(graph.row_ptr), _p(dout), _p(dvalue), _p(dlogit),
-             graph.N, H, layout.c_ref, drop_p, seed, _stream())
+        if ctx.seed_off is None:
+            call("eqf_attn_aggregate_bwd", _p(alpha), _p(value), _p(graph.row_ptr), _p(dout), _p(dvalue), _p(dlogit),
+                 graph.N, H, layout.c_ref, drop_p, seed, _stream())
+        else:
+            call("eqf_attn_aggregate_bwd_dseed", _p(alpha), _p(value), _p(graph.row_ptr), _p(dout), _p(dvalue), _p(dlogit),
+                 graph.N, H, layout.c_ref, drop_p, seed, _p(ctx.seed_off), _stream())
         return dlogit, dvalue, None, None, None, None, None
 
 

@@ -89,6 +89,8 @@ class FlatAdamW(torch.optim.Optimizer):
         if ema_decay is not None:
             self.flat_ema = self.flat_p.clone()
         self._step = 0
+        self._hyper_dev = None  # device {lr, 1 - b1^t, sqrt(1 - b2^t)} of a captured step (equiformer_amd/capture.py)
+        self._hyper_host = None
         self._lag = [0] * len(ps)  # steps a parameter missed because it had no gradient (torch keeps a per-parameter count)
         self._wd_value = [float(wd_of[id(p)]) for p in ps]
         self._skipped = set()  # parameters whose slice of flat_wd currently holds the kernel's "skip" mark (-1)
@@ -167,9 +169,16 @@ class FlatAdamW(torch.optim.Optimizer):
         self._step += 1
         b1, b2 = g0["betas"]
         lr, eps = float(g0["lr"]), float(g0["eps"])
-        call("eqf_adamw_step", _P(self.flat_p), _P(self.flat_g), _P(self.flat_m), _P(self.flat_v), _P(self.flat_wd),
-             _P(self.flat_ema), _P(self._sumsq) if clip else None, self.n, lr, float(b1), float(b2), eps, self._step,
-             float(self.clip_grad or 0.0), float(self.ema_decay or 0.0), st)
+        if self._hyper_dev is not None:  # captured steps (and eager ones beside them): lr and the bias corrections from the device
+            if not torch.cuda.is_current_stream_capturing():  # (a replay is preceded by advance_captured())
+                self.write_hyper()
+            call("eqf_adamw_step_dev", _P(self.flat_p), _P(self.flat_g), _P(self.flat_m), _P(self.flat_v), _P(self.flat_wd),
+                 _P(self.flat_ema), _P(self._sumsq) if clip else None, self.n, _P(self._hyper_dev), float(b1), float(b2), eps,
+                 float(self.clip_grad or 0.0), float(self.ema_decay or 0.0), st)
+        else:
+            call("eqf_adamw_step", _P(self.flat_p), _P(self.flat_g), _P(self.flat_m), _P(self.flat_v), _P(self.flat_wd),
+                 _P(self.flat_ema), _P(self._sumsq) if clip else None, self.n, lr, float(b1), float(b2), eps, self._step,
+                 float(self.clip_grad or 0.0), float(self.ema_decay or 0.0), st)
         for i, o, k, has, sp, sm, sv, se in saved:
             if has:  # same arithmetic as the kernel, with this parameter's own step count
                 t = self._step - self._lag[i]
@@ -189,6 +198,33 @@ class FlatAdamW(torch.optim.Optimizer):
         for i, p in enumerate(self._params):
             self.state[p]["step"] = self._step - self._lag[i]
         return loss
+
+    def device_hyper(self, on=True):
+        """Captured steps (equiformer_amd/capture.py): the step reads lr and the bias corrections from a device array that
+        `write_hyper()` refreshes (the same double-precision host arithmetic as the by-value launch, so the update is bit-equal)."""
+        if on and self._hyper_dev is None:
+            self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=self.flat_p.device)
+            self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        elif not on:
+            self._hyper_dev = self._hyper_host = None
+
+    def write_hyper(self):
+        """{lr, 1 - b1^t, sqrt(1 - b2^t)} of the CURRENT step count -> device (asynchronous copy on the current stream)."""
+        g0 = self.param_groups[0]
+        b1, b2 = g0["betas"]
+        t = max(self._step, 1)
+        # fp32 roundings of the double-precision values, as csrc/optim.hip computes them for the by-value launch
+        self._hyper_host[0] = float(g0["lr"])
+        self._hyper_host[1] = 1.0 - float(b1) ** t
+        self._hyper_host[2] = (1.0 - float(b2) ** t) ** 0.5
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def advance_captured(self):
+        """Host-side bookkeeping of one REPLAY of a captured step (the Python of step() does not run then)."""
+        self._step += 1
+        self.write_hyper()
+        for i, p in enumerate(self._params):
+            self.state[p]["step"] = self._step - self._lag[i]
 
     def load_state_dict(self, state_dict):
         """Restores lr / betas / eps / weight decay of the groups and copies exp_avg / exp_avg_sq / step INTO the flat

@@ -457,6 +457,18 @@ int eqf_attn_aggregate_bwd(const float* alpha, const float* value, const int* ro
                            const eqf_irreps* irreps, float drop_p, unsigned long long seed,
                            void* stream);
 
+/* The same two launches with the dropout seed = seed + *seed_offset, read on the device: a launch captured in a HIP graph
+ * (equiformer_amd/capture.py) draws a fresh mask at every replay when the caller advances the device word in between (the
+ * by-value seed of a captured launch is frozen).  seed_offset may be NULL (= the entry points above).
+ * [ref: the per-step Dropout draw of nets/graph_attention_transformer.py:510-511] */
+int eqf_attn_aggregate_fwd_dseed(const float* logit, const float* value, const int* row_ptr, float* alpha,
+                                 float* out, int N, int H, const eqf_irreps* irreps, float drop_p,
+                                 unsigned long long seed, const unsigned long long* seed_offset, void* stream);
+int eqf_attn_aggregate_bwd_dseed(const float* alpha, const float* value, const int* row_ptr,
+                                 const float* d_out, float* d_value, float* d_logit, int N, int H,
+                                 const eqf_irreps* irreps, float drop_p, unsigned long long seed,
+                                 const unsigned long long* seed_offset, void* stream);
+
 /* ---- dot-product attention (the dp_attention_transformer family) ---------------------------------------------------
  * `irreps` = the H-head irreps of q / k / v rows (segment mul = H * channels-of-head, channels-of-head % 4 == 0,
  * H <= 8).  The key/value row of an edge is 2D wide: in every segment [2l+1][2*mul] the first `mul` channels of an m-row
@@ -550,6 +562,13 @@ int eqf_sumsq(const float* g, long n, float* out, void* stream);
 int eqf_adamw_step(float* p, const float* g, float* m, float* v, const float* wd, float* ema, const float* sumsq,
                    long n, float lr, float beta1, float beta2, float eps, int step, float max_norm, float ema_decay,
                    void* stream);
+/* The same update with {lr, 1 - b1^t, sqrt(1 - b2^t)} read from the device array hyper[3] (fp32, computed by the host in
+ * double as above): the form a HIP-graph-captured train step launches -- by-value arguments are frozen at capture, the host
+ * refreshes the three floats before every replay (equiformer_amd/capture.py).  [ref: the per-step lr of the drivers'
+ * schedulers, engine.py:73-90] */
+int eqf_adamw_step_dev(float* p, const float* g, float* m, float* v, const float* wd, float* ema, const float* sumsq,
+                       long n, const float* hyper, float beta1, float beta2, float eps, float max_norm,
+                       float ema_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -90,3 +90,93 @@ def test_forward_backward_captured_in_a_hip_graph_and_replayed():
                 assert _rel(a, b) < 2e-5
                 n += 1
         assert n > 50
+
+
+def _train_setup(alpha_drop, seed=21):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden as mg
+    from weights import fill_deterministic
+    from equiformer_amd.nets.graph_attention_transformer import GraphAttentionTransformer
+    from equiformer_amd.optim import FlatAdamW
+    from equiformer_amd.synthetic import qm9_like_batch
+    dev = torch.device("cuda:0")
+    m = GraphAttentionTransformer(irreps_in="5x0e", max_radius=5.0, number_of_basis=32, **dict(mg.SMALL_L2, alpha_drop=alpha_drop))
+    m = fill_deterministic(m, seed).to(dev).train()
+    d = {k: v.to(dev) for k, v in qm9_like_batch(6, 12, side=5.5, seed=9).items()}
+    opt = FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-2)
+    return m, opt, d
+
+
+def test_captured_train_step_with_optimizer_equals_eager_over_two_batches_of_one_shape():
+    """equiformer_amd/capture.py: forward + L1 + backward + fused AdamW as one HIP graph per (nodes, edges) shape, the radius graph
+    rebuilt outside it every step INTO the captured tensors.  Two batches of the same shape (the molecules of one in another
+    order: other positions per node, another edge list, the same counts) alternate; parameters after 8 steps -- 3 eager ones,
+    the capture, 4 replays -- equal those of 8 eager steps (dropout off; AdamW's step count and learning rate, changed between
+    steps, reach the captured launch through the device words)."""
+    from equiformer_amd.capture import CapturedTrainStep
+    from equiformer_amd.graph import EdgeGraph
+    results = []
+    for use_graph in (False, True):
+        m, opt, d = _train_setup(0.0)
+        pos_a, z_a, y_a = d["pos"].clone(), d["z"].clone(), d["y"].clone()
+        perm = torch.tensor([3, 0, 5, 1, 4, 2], device=pos_a.device)
+        idx = (perm[:, None] * 12 + torch.arange(12, device=pos_a.device)[None]).reshape(-1)
+        pos_b, z_b, y_b = pos_a[idx].clone(), z_a[idx].clone(), y_a[perm].clone()
+        pos, z, y = pos_a.clone(), z_a.clone(), y_a.clone()  # the static input tensors
+
+        def forward_loss(g):
+            return (m(None, pos, d["batch"], z, graph=g).squeeze() - y).abs().mean()
+
+        def build(into):
+            return EdgeGraph.from_radius(pos, d["batch"], 5.0, num_graphs=6, into=into)
+        cs = CapturedTrainStep(opt, forward_loss, min_eager=3)
+        losses = []
+        for it in range(8):
+            src = (pos_a, z_a, y_a) if it % 2 == 0 else (pos_b, z_b, y_b)
+            pos.copy_(src[0]), z.copy_(src[1]), y.copy_(src[2])
+            for gr in opt.param_groups:
+                gr["lr"] = 1e-3 * (1.0 + 0.1 * it)  # a schedule: the captured launch must see it
+            if use_graph:
+                loss = cs.step(build)
+            else:
+                opt.zero_grad(set_to_none=True)
+                loss = forward_loss(build(None))
+                loss.backward()
+                opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        if use_graph:
+            assert cs.replays == 5 and cs.eager_steps == 3, (cs.replays, cs.eager_steps)
+        results.append((losses, opt.flat_p.detach().clone(), opt.flat_m.detach().clone(), opt._step))
+    (le, pe, me, se), (lg, pg, mg_, sg) = results
+    assert se == sg == 8
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (le, lg)
+    # Atomically accumulated weight gradients differ in summation order from launch to launch (DESIGN 7.6): the moments agree to
+    # that noise; the PARAMETERS agree where the gradient is above it -- Adam's m / (sqrt(v) + eps) turns a noise-level gradient
+    # into a full +-lr step of either sign, in two eager runs as well (tools/capture_debug5.py: 7e-4 after the second eager step).
+    assert _rel(mg_, me) < 5e-4, _rel(mg_, me)
+    big = me.abs() > 1e-3 * me.abs().max()
+    assert int(big.sum()) > 1000
+    assert _rel(pg[big], pe[big]) < 1e-4, _rel(pg[big], pe[big])
+    assert _rel(pg, pe) < 8 * 2e-3  # (nowhere more than the eight steps' learning rates apart)
+
+
+def test_captured_step_draws_a_fresh_dropout_mask_at_every_replay():
+    """alpha_drop > 0, learning rate 0 (the weights do not move): replays of the same batch must give DIFFERENT losses -- the
+    mask seed of a captured launch is host seed + a device word the step rewrites before every replay."""
+    from equiformer_amd.capture import CapturedTrainStep
+    from equiformer_amd.graph import EdgeGraph
+    m, opt, d = _train_setup(0.3)
+    for gr in opt.param_groups:
+        gr["lr"], gr["weight_decay"] = 0.0, 0.0
+
+    def forward_loss(g):
+        return (m(None, d["pos"], d["batch"], d["z"], graph=g).squeeze() - d["y"]).abs().mean()
+
+    def build(into):
+        return EdgeGraph.from_radius(d["pos"], d["batch"], 5.0, num_graphs=6, into=into)
+    cs = CapturedTrainStep(opt, forward_loss, min_eager=2)
+    losses = [float(cs.step(build)) for _ in range(8)]
+    assert cs.replays == 6
+    assert len({round(v, 7) for v in losses[2:]}) >= 5, losses
