@@ -13,6 +13,7 @@ Reference sources of the semantics (paths relative to the reference root):
                                           ScaledScatter :693, EdgeDegreeEmbeddingNetwork :709
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -246,8 +247,17 @@ class RadialBank:
             len(ms) == 7 and ms[0].weight.shape == mods[0][0].weight.shape and ms[3].weight.shape == mods[0][3].weight.shape
             and ms[3].weight.shape[0] == ms[3].weight.shape[1] and ms[0].weight.shape[0] <= 64 for ms in mods)
 
+    # The LAST layer (64 -> weight_numel, 960 for the QM9 model) all G modules at once writes 681 MB at the bench size (E = 25 354),
+    # long before its consumers run and far beyond the 256 MB infinity cache.  Round 6 measured the alternative asked for by the
+    # round-5 review -- each module's last layer when its block asks for the weights (immediately before the block's sfcx forward,
+    # its backward immediately after the block's data gradient, so that w / dw are produced and consumed inside the cache;
+    # EQF_RADIAL_LAST_BANKED=0): the step got SLOWER, 10.08 ms against 9.68-9.71 ms on the same box, twice
+    # (profiles/r06/r06_r_unbank_radial_last_layer_ab.txt) -- seven single-module launches per direction (and fourteen in the
+    # backward) cost more than the grouped ones save in HBM reads.  The banked form stays the default.
+    LAST_BANKED = os.environ.get("EQF_RADIAL_LAST_BANKED", "1") == "1"
+
     def forward(self, edge_scalars):
-        """-> {id(module): [E, weight_numel]}"""
+        """-> {id(module): [E, weight_numel]} (LAST_BANKED) or {id(module): hidden activation [E, 64] of the module's last layer}"""
         ms = self.modules
         G = len(ms)
         C = ms[0].net[0].weight.shape[0]
@@ -256,8 +266,14 @@ class RadialBank:
         h = ops.ln_silu(h, cat([m.net[1].weight for m in ms]), cat([m.net[1].bias for m in ms]), ms[0].net[1].eps, groups=G)
         h = ops.grouped_linear(h, C, [m.net[3].weight for m in ms], [m.net[3].bias for m in ms], wide=True)
         h = ops.ln_silu(h, cat([m.net[4].weight for m in ms]), cat([m.net[4].bias for m in ms]), ms[0].net[4].eps, groups=G)
-        outs = ops.grouped_linear(h, C, [m.net[6].weight for m in ms], [m.offset for m in ms], wide=False)
-        return {id(m): o for m, o in zip(ms, outs)}
+        if self.LAST_BANKED:
+            outs = ops.grouped_linear(h, C, [m.net[6].weight for m in ms], [m.offset for m in ms], wide=False)
+            return {id(m): o for m, o in zip(ms, outs)}
+        return {id(m): hg for m, hg in zip(ms, ops.split_columns(h, G))}
+
+    @staticmethod
+    def last_layer(module, hidden):
+        return ops.dense_linear(hidden, module.net[6].weight, module.offset)  # y = h W^T + offset
 
 
 class GaussianRadialBasisLayer(nn.Module):
@@ -334,7 +350,7 @@ class EdgeContext:
                 self._radial = self._bank.forward(self.edge_scalars)
             w = self._radial.get(id(module))
             if w is not None:
-                return w
+                return w if self._bank.LAST_BANKED else self._bank.last_layer(module, w)
         return module(self.edge_scalars)
 
     def coupling(self, table):

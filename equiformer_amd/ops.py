@@ -774,7 +774,8 @@ def _dense_fwd(x, weight, bias):
     M, K = x.shape
     N = weight.shape[0]
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-    _gemm_group([_desc(1, (x, 0), rows(1, K, 0), (weight, 0), K, (y, 0), rows(1, N, 0), bias, M, N, K)], _stream())
+    # (x may be a column block of a wider row-major tensor: row stride x.stride(0), read in place)
+    _gemm_group([_desc(1, (x, 0), rows(1, x.stride(0), 0), (weight, 0), K, (y, 0), rows(1, N, 0), bias, M, N, K)], _stream())
     return y
 
 
@@ -790,7 +791,8 @@ def _dense_wgrad(x, dy, dw, db=None):
     """dw [N, K] (zero-initialised) += dy^T x; db [N] (zero-initialised, optional) += column sums of dy (same launch)"""
     M, K = x.shape
     N = dy.shape[1]
-    _gemm_group([_desc(3, (dy, 0), rows(1, N, 0), (x, 0), K, (dw, 0), rows(1, K, 0), db, N, K, M)], _stream())
+    # (kind 3: `rc` carries the row stride of x -- possibly a column block of a wider tensor -- and ldb the leading dimension of dw)
+    _gemm_group([_desc(3, (dy, 0), rows(1, N, 0), (x, 0), K, (dw, 0), rows(1, x.stride(0), 0), db, N, K, M)], _stream())
     return dw
 
 
@@ -837,9 +839,11 @@ class _DenseLinear(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        x = _c(x)
+        if not (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and x.stride(0) % 4 == 0
+                and x.storage_offset() % 4 == 0):  # (a column block of a wider tensor is read in place: the radial bank's hidden rows)
+            x = _c(x)
         weight = _c(weight)
-        _chk(x, weight, bias)
+        _chk(x if x.is_contiguous() else x[:1, :1], weight, bias)  # (device / dtype of a row-strided x through its corner)
         y = _dense_fwd(x, weight, bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -879,6 +883,12 @@ class _DenseLinear(Function):
 
 def dense_linear(x, weight, bias=None):
     return _DenseLinear.apply(x, weight, bias)
+
+
+def split_columns(x, G):
+    """G equal column blocks of a row-major [rows, G C] tensor, as views (their consumers read them in place; the backward is one
+    concatenation of the G gradients)"""
+    return x.split(x.shape[1] // G, dim=1)
 
 
 # ------------------------------------------------------------------------------------------------- activations
