@@ -91,7 +91,13 @@ def build(force=False, verbose=True, out=None, extra_flags=(), only=None):
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
-        if (incremental and s != "rowops.hip" and os.path.exists(o)
+        extra = list(EXTRA_FLAGS.get(s, []))
+        # the flags an object was compiled with are recorded beside it: an object left behind by a development build
+        # (EQF_EXTRA_FLAGS) or by an older FLAGS / EXTRA_FLAGS is rebuilt, not linked into the product library
+        flag_file = o + ".flags"
+        flag_text = " ".join(FLAGS + extra + dev)
+        same_flags = os.path.exists(flag_file) and open(flag_file).read() == flag_text
+        if (incremental and s != "rowops.hip" and os.path.exists(o) and same_flags
                 and os.path.getmtime(o) > max(os.path.getmtime(os.path.join(CSRC, s)), newest_header)):
             continue  # object newer than its source and every header (rowops.hip always: it carries the source hash)
         if only is not None and s not in only:
@@ -99,16 +105,19 @@ def build(force=False, verbose=True, out=None, extra_flags=(), only=None):
             if os.path.exists(base):  # (variant builds: the product build's objects of untouched sources are reused)
                 objs[-1] = base
                 continue
-        extra = list(EXTRA_FLAGS.get(s, []))
         if s == "rowops.hip":  # eqf_version() lives there and reports the hash of the sources of THIS build
             extra.append('-DEQF_SOURCE_HASH="%s"' % source_hash())
         cmd = [hipcc] + FLAGS + extra + dev + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
+        if os.path.exists(flag_file):
+            os.remove(flag_file)
+        procs.append((cmd, subprocess.Popen(cmd), flag_file, flag_text))
+    for cmd, p, flag_file, flag_text in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        with open(flag_file, "w") as fh:
+            fh.write(flag_text)
     target = out or LIB
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
     if verbose:

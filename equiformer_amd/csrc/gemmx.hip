@@ -149,11 +149,13 @@ struct LoaderKC {
 template <int NP>
 struct LoaderKS {
   float v[8];
-  float cs;   // running column sum of the fp32 values this thread staged (bias gradients)
+  float cs, cc;  // running column sum of the fp32 values this thread staged (bias gradients), Kahan-compensated: a bias gradient
+                 // is a sum of thousands of cancelling terms, and its rounding noise sat AT the 1e-4 bar of the MD17 second-order
+                 // test (profiles/r05/r05_r_l2_second_order_by_matrix_mode.txt)
   int kleft;  // of the step in flight: valid reduction rows of this thread's group of 8 (may be <= 0); < 0 for a column past X
   int kb, q, rem;  // this thread's first reduction row of the NEXT step, and its two-level index
   __device__ __forceinline__ void init(const GRows& R, int k_first) {
-    cs = 0.f;
+    cs = 0.f, cc = 0.f;
     kb = k_first + 8 * (threadIdx.x >> 6);
     q = kb / R.d;
     rem = kb - q * R.d;
@@ -185,7 +187,10 @@ struct LoaderKS {
       if (j >= kleft) v[j] = 0.f;
     if (want_cs) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) cs += v[j];
+      for (int j = 0; j < 8; ++j) {
+        const float y = v[j] - cc, t = cs + y;
+        cc = (t - cs) - y, cs = t;
+      }
     }
     __bf16 p[NP][8];
     split_n<NP>(v, 8, p);
@@ -622,12 +627,17 @@ __global__ __launch_bounds__(64, 2) void gemmx_tn_direct_kernel(const GXGroup g_
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  float csa = 0.f, csb = 0.f;
+  float csa = 0.f, csb = 0.f, cca = 0.f, ccb = 0.f;  // (Kahan-compensated column sums, as in LoaderKS)
 #pragma unroll
   for (int kt = 0; kt < GD_KC / 16; ++kt) {
     if (16 * kt < kend) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) csa += a[kt][j], csb += b[kt][j];
+      for (int j = 0; j < 8; ++j) {
+        const float ya = a[kt][j] - cca, ta = csa + ya;
+        cca = (ta - csa) - ya, csa = ta;
+        const float yb = b[kt][j] - ccb, tb = csb + yb;
+        ccb = (tb - csb) - yb, csb = tb;
+      }
       bf16x8 pa[NA], pb[NA];
       split_planes<NA>(a[kt], pa);
       split_planes<NA>(b[kt], pb);

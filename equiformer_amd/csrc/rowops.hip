@@ -715,6 +715,8 @@ int eqf_gate_fwd(const float* in, float* out, int rows, int S, const eqf_irreps*
 int eqf_gate_bwd(const float* in, const float* d_out, float* d_in, int rows, int S, const eqf_irreps* gated,
                  float c_silu, float c_sig, void* stream) {
   if (!in || !d_out || !d_in || !gated) return EQF_E_BADARG;
+  for (int s = 0; s < gated->nseg; ++s)
+    if (gated->l[s] > 3) return EQF_E_UNSUPPORTED;  // the gate-scalar gradient of gate_bwd_cols_kernel holds 2 l + 1 <= 7 components
   if (rows <= 0) return 0;
   const GateTab T = make_gatetab(S, *gated);
   const int RB = 8;

@@ -500,8 +500,16 @@ def _from_alias(a):
     return torch.empty(0, dtype=torch.float32, device=dev).set_(stor, off, (n,))
 
 
-def _launch_queue(q):
+def _launch_queue(q, early=False):
+    """early: a flush from inside the pass (gradient hooks).  Only the entries whose parameter has ALREADY been accumulated go out
+    then: while .grad is still None the zero tensor backward() returned may have been summed OUT of place with another
+    contribution of the same parameter (a weight used several times: the engine's input buffer), and a launch into the dead
+    zero tensor would lose the gradient; those entries wait for the end of the pass (round-5 advisor finding)."""
     entries, q.entries = q.entries, []
+    if early:
+        ready = [e for e in entries if e[0].grad is not None and (not e[5] or e[1].grad is not None)]
+        q.entries = [e for e in entries if not (e[0].grad is not None and (not e[5] or e[1].grad is not None))]
+        entries = ready
     descs = []
     for (w, b, x, dy, spec, fused_b, aw, ab) in entries:
         # where the gradient lives now: the zero tensor backward() returned -- adopted as .grad by AccumulateGrad, or still on
@@ -532,7 +540,21 @@ def flush_deferred_weight_gradients():
         return
     q = _task_queues.get(task)
     if q is not None and q.entries:
-        _launch_queue(q)
+        _launch_queue(q, early=True)
+
+
+def _hooked(p):
+    """Somebody reads this parameter's gradient DURING backward -- a tensor hook, a post-accumulate-grad hook, or (not visible
+    from Python) a hook on its AccumulateGrad node, which is what torch DistributedDataParallel's reducer installs: at that
+    moment a deferred gradient is still the zero tensor.  FlatGradAllReduce marks its parameters (`_eqf_flushes`): its hook
+    flushes the queue before it reads.  Any other hook, and any initialised process group without that mark (stock DDP: wrong
+    gradients at world size 1 already, round-5 advisor finding), switches deferral off for the parameter."""
+    if getattr(p, "_eqf_flushes", False):
+        return False
+    if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+        return True
+    dist = torch.distributed
+    return bool(dist.is_available() and dist.is_initialized())
 
 
 def _accumulates_into_grad(p):
@@ -548,7 +570,8 @@ def _can_defer(*params):
     """plain first-order .backward(), leaf parameters without an existing .grad (an existing one is added to OUT of place or in
     place depending on the engine's mood: those gradients are computed at once)"""
     return (_defer_wgrad[0] and not torch.is_grad_enabled()
-            and all(p is None or (p.is_leaf and p.requires_grad and p.grad is None and _accumulates_into_grad(p))
+            and all(p is None or (p.is_leaf and p.requires_grad and p.grad is None and not _hooked(p)
+                                  and _accumulates_into_grad(p))
                     for p in params))
 
 

@@ -66,6 +66,10 @@ class FlatGradAllReduce:
         # post-accumulate hook; the collective is launched by whichever arrives LAST, in whatever order autograd runs the
         # nodes.  (One backward() per reduce(): with several micro-batch backwards the first one would launch it.)
         self.split = len(self.params)
+        for p in self.params:
+            # this reducer's hook flushes the deferred weight gradients before it reads (ops._hooked): deferral stays on for
+            # its parameters although a process group / gradient hooks exist
+            p._eqf_flushes = True
         self._handles = []
         self._arrived = set()
         self._pending = None

@@ -145,6 +145,7 @@ def test_early_flush_from_a_gradient_hook(recorder):
     """FlatGradAllReduce's tail hook: what is queued when a post-accumulate-grad hook fires is launched there, the rest of
     the pass at its end."""
     w1, w2 = torch.randn(4, 3, requires_grad=True), torch.randn(3, 2, requires_grad=True)
+    w1._eqf_flushes = w2._eqf_flushes = True  # what FlatGradAllReduce sets: "my hook flushes before it reads"
     x = torch.randn(5, 4)
     seen = []
 
@@ -188,3 +189,80 @@ def test_switch_conditions(recorder):
 
     Probe.apply(torch.randn(2, 3), w).sum().backward()
     assert res == {"leaf": True, "nonleaf": False, "nograd": False, "create_graph": False, "off": False}
+
+
+def test_a_foreign_gradient_hook_switches_deferral_off_for_its_parameter(recorder):
+    """anything that reads a gradient DURING backward (tensor hooks, post-accumulate hooks, DDP's bucket hooks)
+    would see the zero tensor of a deferred gradient.  A parameter with a hook that does not declare the flush is not deferred:
+    the hook sees the real gradient; the other parameter still is."""
+    w1, w2 = torch.randn(4, 3, requires_grad=True), torch.randn(3, 2, requires_grad=True)
+    x = torch.randn(5, 4)
+    seen = {}
+    h1 = w2.register_post_accumulate_grad_hook(lambda p: seen.__setitem__("post", p.grad.clone()))
+    h2 = w1.register_hook(lambda g: seen.__setitem__("tensor", g.clone()))
+    y = _Lin.apply(_Lin.apply(x, w1, "first", False), w2, "second", False)
+    y.sum().backward()
+    h1.remove(), h2.remove()
+    assert not recorder and _queued() == 0  # both parameters are hooked: nothing was queued
+    ref1, ref2 = torch.autograd.grad(((x @ w1) @ w2).sum(), [w1, w2])
+    assert torch.allclose(seen["post"], ref2, atol=1e-6) and torch.allclose(seen["tensor"], ref1, atol=1e-6)
+    assert torch.allclose(w1.grad, ref1, atol=1e-6) and torch.allclose(w2.grad, ref2, atol=1e-6)
+
+
+def test_early_flush_keeps_entries_whose_parameter_is_not_accumulated_yet(recorder, monkeypatch):
+    """a weight used three times; a (flush-declaring) hook on a layer in between fires while the shared
+    weight's .grad is still None and its first deferred zero tensor has already been summed out of place with the second
+    contribution.  The early flush must leave that entry queued (a launch into the dead zero tensor would lose it); at the end of
+    the pass every queued entry is aimed at the tensor that IS .grad."""
+    launched = []
+    monkeypatch.setattr(ops, "_gemm_group", lambda descs, st: launched.append(list(descs)))
+    w = torch.randn(4, 4, requires_grad=True)
+    v = torch.randn(4, 4, requires_grad=True)
+    w._eqf_flushes = v._eqf_flushes = True
+    x = torch.randn(5, 4)
+    h = v.register_post_accumulate_grad_hook(lambda p: ops.flush_deferred_weight_gradients())
+    # v sits between the uses of w: its AccumulateGrad (and the hook) runs while w still waits for its remaining contributions
+    y = _Lin.apply(_Lin.apply(_Lin.apply(_Lin.apply(x, w, "w-1", False), w, "w-2", False), v, "v", False), w, "w-3", False)
+    y.sum().backward()
+    h.remove()
+    tags = [[d[2] for d in g] for g in launched]
+    # the hook's early flush launched v only (w.grad was still None); everything of w went out when the pass ended
+    assert tags[0] == ["v"], tags
+    assert sorted(t for g in tags[1:] for t in g) == ["w-1", "w-2", "w-3"], tags
+    assert all(d[0] == w.grad.data_ptr() for g in launched[1:] for d in g)  # ... into the tensor that IS .grad, not a dead zero tensor
+
+
+def test_an_initialised_process_group_without_the_reducer_switches_deferral_off(recorder):
+    """Stock DistributedDataParallel hangs its bucket hooks on the AccumulateGrad nodes (not visible from Python): with a process
+    group up and parameters that no FlatGradAllReduce has marked, nothing is deferred and DDP's gradients are exact."""
+    import socket
+    import torch.distributed as dist
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.w1 = torch.nn.Parameter(torch.randn(4, 3))
+                self.w2 = torch.nn.Parameter(torch.randn(3, 2))
+
+            def forward(self, x):
+                return _Lin.apply(_Lin.apply(x, self.w1, "first", False), self.w2, "second", False)
+        net = Net()
+        ddp = torch.nn.parallel.DistributedDataParallel(net)
+        x = torch.randn(5, 4)
+        ddp(x).sum().backward()
+        assert not recorder and _queued() == 0
+        ref1, ref2 = torch.autograd.grad(((x @ net.w1) @ net.w2).sum(), [net.w1, net.w2])
+        assert torch.allclose(net.w1.grad, ref1, atol=1e-6) and torch.allclose(net.w2.grad, ref2, atol=1e-6)
+        # ... and FlatGradAllReduce's parameters keep it (the reducer's own hook flushes first)
+        from equiformer_amd.parallel import FlatGradAllReduce
+        net2 = Net()
+        FlatGradAllReduce(net2)
+        with torch.no_grad():
+            assert not ops._hooked(net2.w1) and ops._hooked(torch.nn.Parameter(torch.randn(2)))
+    finally:
+        dist.destroy_process_group()

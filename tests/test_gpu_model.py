@@ -335,8 +335,13 @@ def test_md17_l2_bench_batch_energy_forces_and_force_loss_gradients():
     # SECOND-ORDER parameter gradients at this batch are held to 2e-4 of each tensor's largest entry: the worst tensor is a
     # 64-element bias gradient of a radial MLP (blocks.3...dtp_rad.net.0.bias), a sum over 3 342 edges of cancelling fp32 terms,
     # and it measures 1.00e-4 with the exact-fp32 MFMA in every matrix step, 1.01e-4 with 3 x 3 planes and 1.10e-4 in the default
-    # split mode (tools/l2_modes_probe.py, profiles/r05/r05_r_l2_second_order_by_matrix_mode.txt): fp32 summation noise at the
-    # size of the bar itself, not the bf16 planes.  Every other tensor of the 210 is below 1e-4 (next: 9.9e-5, 6.1e-5, 5.8e-5).
+    # split mode (tools/l2_modes_probe.py, profiles/r05/r05_r_l2_second_order_by_matrix_mode.txt): fp32 noise at the size of the
+    # bar itself, not the bf16 planes.  Every other tensor of the 210 is below 1e-4 (next: 9.9e-5, 6.1e-5, 5.8e-5).  Round 6 tried
+    # the fix the round-5 review proposed -- Kahan-compensated column sums for the bias gradients (csrc/gemmx.hip) -- and the
+    # figure did not move (1.1047e-4 in three runs): the three worst tensors are the biases of ONE radial MLP (blocks.3 sep_act,
+    # layers 0 / 1 / 3), i.e. the noise is already in the gradient that reaches that MLP through the double backward of block 3's
+    # fused tensor product, not in the final sum.  The bar for E and F (north_star) is untouched.
+    print("md17_l2_bench8 worst second-order parameter gradients:", worst[:5])
     assert len(worst) > 100 and worst[0][0] < 2e-4, worst[:5]
     assert sum(1 for e, _ in worst if e >= 1e-4) <= 2, worst[:5]
 
