@@ -237,8 +237,9 @@ def build_workload(args, dev, rank, world):
 
     def step_graph():
         return captured.step(build_graph)
+    reducer.timing = world > 1
     return dict(step=step_graph if captured is not None else step_eager, step_eager=step_eager, units=units, nodes=g.N,
-                edges=g.E, text=text, model_name=W["model"], captured=captured)
+                edges=g.E, text=text, model_name=W["model"], captured=captured, reducer=reducer)
 
 
 def cpu_baseline_other(args):
@@ -441,6 +442,15 @@ def measure(args, dev, rank, world, workload, mode, steps, warmup, regions=("sfc
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         if world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            # what the data-parallel step adds, per rank: reduce() = head collective + the part of the tail collective that
+            # backward did not hide; and the shard sizes the ranks actually had
+            ar = wl["reducer"].reduce_ms()
+            info = torch.tensor([float(wl["edges"]), float(wl["nodes"]), -1.0 if ar is None else ar], device=dev, dtype=torch.float64)
+            allinfo = [torch.zeros_like(info) for _ in range(world)]
+            torch.distributed.all_gather(allinfo, info)
+            wl["per_rank"] = {"edges_per_gpu": [int(v[0].item()) for v in allinfo], "nodes_per_gpu": [int(v[1].item()) for v in allinfo],
+                              "allreduce_ms": [round(v[2].item(), 4) for v in allinfo],
+                              "n_ranks_seen": torch.distributed.get_world_size()}
         out.append((t.item(), prof, flt))
         wl["deferred_weight_gradients"] = dict(ops.deferred_weight_gradient_stats(), steps=steps)
     loss = float(loss.item())
@@ -570,6 +580,11 @@ def main():
                 "deferred_weight_gradients": wl.get("deferred_weight_gradients"),
             },
         }
+        if world > 1 and wl.get("per_rank"):
+            pr = wl["per_rank"]
+            out["n_ranks_seen"] = pr["n_ranks_seen"]
+            out["allreduce_ms"] = max(pr["allreduce_ms"])  # per step: head collective + exposed wait on the tail, slowest rank
+            out["config"]["per_rank"] = pr
         vals = [wl["units"] * world * args.steps / d for d, _, _ in regs]
         what = {"graph": "the step replayed as one HIP graph", "": "eager launches, events on every matrix-core launch",
                 None: "eager launches, no events"}

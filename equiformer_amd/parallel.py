@@ -71,6 +71,7 @@ class FlatGradAllReduce:
             # its parameters although a process group / gradient hooks exist
             p._eqf_flushes = True
         self._handles = []
+        self._marks = []
         self._arrived = set()
         self._pending = None
         self._tail_done = False
@@ -98,6 +99,31 @@ class FlatGradAllReduce:
             return
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.group)
+
+    # ---- optional timing of what reduce() adds to a step: the head collective + whatever of the tail collective backward
+    # did not hide (bench.py `allreduce_ms`).  Device tensors: HIP events on the current stream; CPU tensors: the host clock.
+    timing = False
+
+    def _mark(self):
+        if self.flat.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    def reduce_ms(self, reset=True):
+        """mean milliseconds per reduce() since the last reset (synchronises the device), or None without samples"""
+        if not getattr(self, "_marks", None):
+            return None
+        if self.flat.is_cuda:
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in self._marks]
+        else:
+            ms = [1e3 * (b - a) for a, b in self._marks]
+        if reset:
+            self._marks = []
+        return sum(ms) / len(ms)
 
     def _pack(self, lo, hi):
         """gradients of parameters [lo, hi) -> their slices of the flat buffer (multi-tensor copy: a handful of launches)"""
@@ -167,6 +193,7 @@ class FlatGradAllReduce:
                 self._pending = self._all_reduce(self.flat[self.offsets[self.split]:], async_op=True)
         self._pack(0, self.split)
         if active:
+            mark = self._mark() if self.timing else None
             head = self.flat[:self.offsets[self.split]] if split else self.flat
             _, need_div_head = self._all_reduce(head, async_op=False)
             if need_div_head:
@@ -176,6 +203,8 @@ class FlatGradAllReduce:
                 work.wait()
                 if need_div:
                     self.flat[self.offsets[self.split]:].div_(ws)
+            if mark is not None:
+                self._marks.append((mark, self._mark()))
         self._pending, self._tail_done = None, False
         self._arrived.clear()
         for p, v in zip(self.params, self.views):

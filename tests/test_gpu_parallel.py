@@ -210,3 +210,24 @@ def test_bench_gpus_2_runs_by_itself(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 32
     dw = d["config"]["deferred_weight_gradients"]
     assert dw["queued"] > 0 and dw["flushes"] >= 2 * dw["steps"], dw
+
+
+def test_bench_gpus_8_runs_by_itself_on_one_gpu(tmp_path):
+    """`--gpus 8` must not fail on first contact with an 8-GPU node.  Eight ranks share cuda:0 over gloo here
+    (tiny batch): the line carries the rank count the process group saw, every rank's shard size and what reduce() added per step."""
+    import json
+    import subprocess
+    env = dict(os.environ, EQF_BENCH_BACKEND="gloo", EQF_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--repeats", "1", "--no-cpu-baseline", "--no-sub-records", "--prewarm-s", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 32
+    pr = d["config"]["per_rank"]
+    assert len(pr["edges_per_gpu"]) == 8 and all(e > 0 for e in pr["edges_per_gpu"]) and len(set(pr["edges_per_gpu"])) > 1
+    assert d["allreduce_ms"] > 0 and all(v > 0 for v in pr["allreduce_ms"])
+    assert d["config"]["hip_graph"] is False  # data-parallel steps launch eagerly (the reducer's collectives are not captured)

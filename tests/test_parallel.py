@@ -291,3 +291,74 @@ def test_shard_balanced_equalises_edge_counts():
         naive = [sum(srt[r * per:(r + 1) * per]) for r in range(w)]
         bal = [sum(srt[i] for i in s) for s in shard_balanced(srt, w)]
         assert max(bal) - min(bal) <= max(naive) - min(naive)
+
+
+def _loss_sum(model, d, idx, denom):
+    """L1 summed over the molecules `idx`, divided by `denom` (the per-rank share of the global batch): the AVERAGE over ranks
+    of these losses is the global mean whatever the shard sizes."""
+    n = d["pos"].shape[0] // d["y"].shape[0]
+    sel = torch.cat([torch.arange(i * n, (i + 1) * n) for i in idx])
+    batch = torch.repeat_interleave(torch.arange(len(idx)), n)
+    y = model(None, d["pos"][sel], batch, d["z"][sel]).squeeze(-1)
+    return (y - d["y"][list(idx)]).abs().sum() / denom
+
+
+def _edge_costs(d, nmol, r=5.0):
+    n = d["pos"].shape[0] // nmol
+    p = d["pos"].view(nmol, n, 3)
+    dist2 = ((p[:, :, None] - p[:, None]) ** 2).sum(-1)
+    return [int(((dist2[i] < r * r).sum() - n).item()) for i in range(nmol)]
+
+
+def _worker8(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from equiformer_amd.parallel import FlatGradAllReduce, shard_balanced
+    from equiformer_amd.synthetic import qm9_like_batch
+    model = _small_model()
+    red = FlatGradAllReduce(model)
+    red.broadcast_parameters()
+    nmol = 19  # 19 molecules over 8 ranks: shards of 3 and 2
+    d = qm9_like_batch(nmol, 8, side=4.5, seed=11)
+    shards = shard_balanced(_edge_costs(d, nmol), world)
+    idx = shards[rank]
+    if rank == 3:  # this rank's tail hook never fires: reduce() has to issue the tail collective itself, in the same order
+        for h in red._handles:
+            h.remove()
+    model.zero_grad()
+    _loss_sum(model, d, idx, nmol / world).backward()
+    hooked = bool(red._tail_done)
+    flat = red.reduce().clone()
+    torch.save({"flat": flat, "idx": list(idx), "hooked": hooked, "world": dist.get_world_size()},
+               os.path.join(out, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_uneven_balanced_shards_match_full_batch(tmp_path):
+    """nothing had exercised more than two ranks.  Eight gloo ranks, 19 molecules dealt by `shard_balanced` on
+    their edge counts (shards of 3 and 2 molecules), one rank whose backward hook does not fire: every rank ends with the SAME
+    flat gradient, equal to the single-process gradient of the whole batch; the collective sequence (tail, then head) cannot
+    depend on the hook -- a mismatch would hang or corrupt, here it would time out."""
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(world)]
+    assert all(r["world"] == world for r in rs)
+    assert sorted(i for r in rs for i in r["idx"]) == list(range(19))
+    assert sorted(len(r["idx"]) for r in rs) == [2] * 5 + [3] * 3
+    assert not rs[3]["hooked"] and all(r["hooked"] for k, r in enumerate(rs) if k != 3)
+    for r in rs[1:]:
+        assert torch.equal(rs[0]["flat"], r["flat"]), "ranks disagree on the reduced gradient"
+    sys.path.insert(0, ROOT)
+    from equiformer_amd.synthetic import qm9_like_batch
+    model = _small_model()
+    d = qm9_like_batch(19, 8, side=4.5, seed=11)
+    _loss_sum(model, d, range(19), 19.0).backward()
+    full = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                      for p in model.parameters() if p.requires_grad])
+    got = _unpad(rs[0]["flat"], [p.numel() for p in model.parameters() if p.requires_grad])
+    err = ((full - got).abs().max() / full.abs().max()).item()
+    assert err < 1e-5, err
