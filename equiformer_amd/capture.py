@@ -80,7 +80,7 @@ class CapturedTrainStep:
         # gradients / activations the graph's private pool hands out
         self.opt.device_hyper(True)
         graph = torch.cuda.CUDAGraph()
-        with ops.dropout_seed_offset(self._seed_dev):
+        with ops.dropout_seed_offset(self._seed_dev), ops._arena.capture_scope():
             step_before = self.opt._step
             with torch.cuda.graph(graph):
                 loss = self._run(g)

@@ -172,20 +172,35 @@ class _ZeroArena:
 
     def __init__(self):
         self.slabs = {}
+        self.capture_slabs = None  # a dict while a capture that declared itself is running (capture_scope)
 
     def take(self, numel, device):
-        if numel == 0 or numel > self.MAX_REQ or device.type != "cuda" or _capturing():
-            # (under HIP-graph capture every accumulator gets its own fill NODE: a replay must zero it again, and a slab that
-            # was filled before the capture would be accumulated into once per replay)
+        cap = _capturing()
+        if numel == 0 or numel > self.MAX_REQ or device.type != "cuda" or (cap and self.capture_slabs is None):
+            # (under a HIP-graph capture that did not open a capture_scope every accumulator gets its own fill NODE: a replay
+            # must zero it again, and a slab that was filled before the capture would be accumulated into once per replay)
             return torch.zeros(numel, device=device, dtype=torch.float32)
+        # inside a capture_scope the slabs are allocated DURING the capture (their fill is a node of the graph, replayed with
+        # it) and dropped when the scope ends: ~4 fill nodes per QM9 step instead of 116 (5 % of the replayed step, round 6)
+        slabs = self.capture_slabs if cap else self.slabs
         idx = device.index if device.index is not None else torch.cuda.current_device()
         key = (idx, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
-        slab, used = self.slabs.get(key, (None, 0))
+        slab, used = slabs.get(key, (None, 0))
         need = (numel + 63) & ~63
         if slab is None or used + need > self.SLAB:
             slab, used = torch.zeros(self.SLAB, device=device, dtype=torch.float32), 0
-        self.slabs[key] = (slab, used + need)
+        slabs[key] = (slab, used + need)
         return slab[used:used + numel]
+
+    @contextlib.contextmanager
+    def capture_scope(self):
+        """Around a stream capture (equiformer_amd/capture.py): accumulators of the captured launches share slabs of their own."""
+        prev = self.capture_slabs
+        self.capture_slabs = {}
+        try:
+            yield
+        finally:
+            self.capture_slabs = prev
 
 
 _arena = _ZeroArena()
