@@ -55,6 +55,9 @@ struct SfcCommon {
 struct SfcOrder {
   int mode, nx, ny, per_xcd;
 };
+#ifndef X_LPT_BATCH
+#define X_LPT_BATCH 8  // tiles per XCD and batch of order mode 4
+#endif
 // false: surplus workgroup of the padded grid
 __device__ __forceinline__ bool order_xy(const SfcOrder& o, int b, int& x, int& y) {
   if (o.mode == 0) {
@@ -70,6 +73,19 @@ __device__ __forceinline__ bool order_xy(const SfcOrder& o, int b, int& x, int& 
     const int k = b & 7, s = b >> 3;
     y = s / o.per_xcd;
     x = 8 * (s - y * o.per_xcd) + k;
+    return x < o.nx && y < o.ny;
+  }
+  if (o.mode == 4) {
+    // As mode 3, in BATCHES of X_LPT_BATCH tiles per XCD: heaviest items first inside a batch, batch after batch.  With the
+    // whole launch item-major (mode 3) the seven data-gradient items of a tile ran at unrelated times and each re-read the
+    // tile's d_out rows from HBM: 728 MB per launch against 332 MB tile-major (rocprofv3 FETCH_SIZE, profiles/r06/r06_u); a
+    // batch keeps the rows of its tiles in the XCD's L2 while its items run, and the tail of short items still forms at the
+    // end of every batch.
+    const int k = b & 7, s = b >> 3;
+    const int per_batch = X_LPT_BATCH * o.ny;
+    const int bt = s / per_batch, r = s - bt * per_batch;
+    y = r / X_LPT_BATCH;
+    x = 8 * (bt * X_LPT_BATCH + (r - y * X_LPT_BATCH)) + k;
     return x < o.nx && y < o.ny;
   }
   const int L = (o.mode == 1) ? (b & 7) * o.per_xcd + (b >> 3) : b;

@@ -280,10 +280,11 @@ inline int gate_map(const XGate& gt, const eqf_dtp_paths* P, int in_off, int mul
 #ifndef EQF_X_LPT
 #define EQF_X_LPT 1
 #endif
-inline SfcOrder lpt_order(int nx, int ny, int& nblocks) {
+inline SfcOrder lpt_order(int nx, int ny, int& nblocks, bool batched = false) {
   SfcOrder o;
-  o.mode = 3, o.nx = nx, o.ny = ny;
+  o.mode = batched ? 4 : 3, o.nx = nx, o.ny = ny;
   o.per_xcd = (nx + 7) / 8;
+  if (batched) o.per_xcd = ((o.per_xcd + X_LPT_BATCH - 1) / X_LPT_BATCH) * X_LPT_BATCH;  // whole batches
   nblocks = 8 * o.per_xcd * ny;
   return o;
 }
@@ -545,7 +546,7 @@ inline int plan_bwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XBwdAr
   A.ms = (msmax + 3) & ~3;  // the transposition tile behind the coupling block stays 16-byte aligned
   lds = (size_t)(32 * A.ms + (1 + 5) * XT_FLOATS) * sizeof(float);  // coupling block + x / w / dx / dw tile + one d_out tile per m3
 #if EQF_X_LPT
-  A.ord = lpt_order(eqf_cdiv(C.E, 32), ngrp, nblk);
+  A.ord = lpt_order(eqf_cdiv(C.E, 32), ngrp, nblk, true);
 #else
   A.ord = xcd_order(eqf_cdiv(C.E, 32), ngrp, nblk);
 #endif

@@ -50,6 +50,12 @@ def _order_xy(b, nx, ny, per_xcd, mode=1):
         y = s // per_xcd
         x = 8 * (s - y * per_xcd) + k
         return (x, y) if (x < nx and y < ny) else None
+    if mode == 4:  # mode 3 in batches of 8 tiles per XCD
+        k, s = b & 7, b >> 3
+        bt, r = divmod(s, 8 * ny)
+        y = r // 8
+        x = 8 * (bt * 8 + (r - y * 8)) + k
+        return (x, y) if (x < nx and y < ny) else None
     Lg = (b & 7) * per_xcd + (b >> 3)
     if Lg >= nx * ny:
         return None
