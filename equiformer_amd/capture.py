@@ -14,9 +14,13 @@ What stays OUTSIDE the graph, and why:
     the attention dropout (a fresh draw per replay: eqf_attn_aggregate_*_dseed) and {lr, 1 - b1^t, sqrt(1 - b2^t)} of AdamW
     (eqf_adamw_step_dev); the host writes them (pinned buffer, asynchronous copy) before it launches the graph.
 
+The MD17 force-loss step (forces by a create_graph backward inside the forward, then a second-order backward) is captured the
+same way (tests/test_gpu_capture.py; bench.py --workload md17_l2: 463 -> 619 frames/s, md17_l3: 218 -> 254).
+
 Limits: one process / one GPU (a data-parallel reducer's collectives stay eager: `CapturedTrainStep` refuses a reducer),
-first-order backward only (the MD17 force loss differentiates the backward: not captured), inputs other than the graph at
-fixed addresses (`forward_loss` reads the same tensors every step; copy a new batch into them)."""
+attention dropout together with a create_graph backward (no model of the reference combines them), radius graphs only (the
+periodic OC20 graph builds its by-source view with a device sort: eager), inputs other than the graph at fixed addresses
+(`forward_loss` reads the same tensors every step; copy a new batch into them)."""
 import torch
 
 from . import ops

@@ -70,9 +70,13 @@ class GraphAttentionTransformerMD17(_Trunk):
     differentiable_forces_in_eval = False
 
     @torch.enable_grad()
-    def forward(self, node_atom, pos, batch):
+    def forward(self, node_atom, pos, batch, graph=None):
+        """graph: (extension of the reference signature) the radius graph of `pos`, built by the caller -- what a train step
+        captured in a HIP graph passes (equiformer_amd/capture.py: the graph's edge count is read back on the host, outside the
+        capture)."""
         pos = pos.to(torch.float32).contiguous().requires_grad_(True)
-        graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=1000)
+        if graph is None:
+            graph = EdgeGraph.from_radius(pos, batch, self.max_radius, max_num_neighbors=1000)
         atom_embedding, _, _ = self.atom_embed(node_atom)
         trainable = any(p.requires_grad for p in self.parameters())
         second_order = (self.training or self.differentiable_forces_in_eval) and trainable

@@ -180,3 +180,51 @@ def test_captured_step_draws_a_fresh_dropout_mask_at_every_replay():
     losses = [float(cs.step(build)) for _ in range(8)]
     assert cs.replays == 6
     assert len({round(v, 7) for v in losses[2:]}) >= 5, losses
+
+
+def test_captured_md17_force_loss_step_equals_eager():
+    """BASELINE configs #3 / #4 are force-loss steps: forward, forces by a create_graph backward, loss, SECOND-order backward,
+    AdamW.  The whole of it replays as one HIP graph (bench.py --workload md17_l2 / md17_l3); here two aspirin frames of the
+    L_max = 2 model: loss trajectory and moments of 3 eager + 4 replayed steps against 7 eager ones."""
+    from equiformer_amd import nets
+    from equiformer_amd.capture import CapturedTrainStep
+    from equiformer_amd.graph import EdgeGraph
+    from equiformer_amd.optim import FlatAdamW
+    from equiformer_amd.synthetic import md17_aspirin_batch
+    dev = torch.device("cuda:0")
+    results = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        m = nets.model_entrypoint("graph_attention_transformer_nonlinear_exp_l2_md17")(irreps_in="64x0e", radius=5.0, num_basis=32)
+        m = m.to(dev).train()
+        d = {k: v.to(dev) for k, v in md17_aspirin_batch(2, seed=3).items()}
+        gen = torch.Generator().manual_seed(7)
+        ty, tf = torch.randn(2, 1, generator=gen).to(dev), torch.randn(42, 3, generator=gen).to(dev)
+        opt = FlatAdamW(m.parameters(), lr=5e-4, weight_decay=1e-6)
+
+        def forward_loss(g):
+            E, F = m(node_atom=d["z"], pos=d["pos"], batch=d["batch"], graph=g)
+            return (E - ty).abs().mean() + 80.0 * (F - tf).norm(dim=1).mean()
+
+        def build(into):
+            return EdgeGraph.from_radius(d["pos"], d["batch"], 5.0, num_graphs=2, into=into)
+        cs = CapturedTrainStep(opt, forward_loss, min_eager=3)
+        losses = []
+        for it in range(7):
+            if use_graph:
+                loss = cs.step(build)
+            else:
+                opt.zero_grad(set_to_none=True)
+                loss = forward_loss(build(None))
+                loss.backward()
+                opt.step()
+                loss = loss.detach()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        if use_graph:
+            assert cs.replays == 4 and cs.eager_steps == 3
+        results.append((losses, opt.flat_m.detach().clone()))
+    (le, me), (lg, mg_) = results
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (le, lg)
+    assert _rel(mg_, me) < 2e-3, _rel(mg_, me)

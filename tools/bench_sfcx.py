@@ -86,6 +86,12 @@ def run(name, irr, sh_irr, out_irr, n2, use_w, want_dM=False):
         for tag, fn in (("fwd", fx), ("bwd_weight", wx)):
             us = timeit(fn)
             print("%-10s mode %d %-10s %7.1f us  (%5.1f TFLOP/s)" % (name, mode, tag, us, flops / us / 1e6), flush=True)
+        if "--wclasses" in sys.argv:  # the weight-gradient launch with the items of one (input degree, output degree) class only
+            for di in (1, 3, 5):
+                for do in (1, 3, 5):
+                    L.eqf_sfcx_dev_set(3, 1 + 10 * di + do)
+                    print("%-10s            wgrad items of (d1, d3) = (%d, %d) only: %7.1f us" % (name, di, do, timeit(wx)), flush=True)
+            L.eqf_sfcx_dev_set(3, 0)
 
 
 run("sep_act", "128x0e+64x1e+32x2e", "1x0e+1x1e+1x2e", "224x0e+64x1e+32x2e", 128, True)
