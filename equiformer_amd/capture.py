@@ -64,13 +64,17 @@ class CapturedTrainStep:
         # the radius graph of this batch: into the tensors of a captured shape when one fits (tried most recent first)
         g = None
         for key, rec in reversed(list(self._graphs.items())):
+            if not getattr(rec["sg"], "_radius_static", False):  # (abandoned by a build that found another edge count)
+                del self._graphs[key]
+                continue
+            self._draw_seed()  # (the device words go out BEFORE the graph build's host read-back: they overlap it)
             g = build_graph(rec["sg"])
             if g is rec["sg"]:
-                self._draw_seed()
                 self.opt.advance_captured()
                 rec["graph"].replay()
                 self.replays += 1
                 return rec["loss"]
+            del self._graphs[key]  # its tensors were overwritten by the build of another shape: the graph is gone
             break  # (one rebuild attempt per step: a second one would repeat the neighbour search)
         if g is None:
             g = build_graph(None)

@@ -88,12 +88,17 @@ class EdgeGraph:
         call("eqf_segment_ptr", _P(b32), N, int(num_graphs), _P(mol_ptr), _P(stats, 4), st)
         deg = torch.empty(N, dtype=torch.int32, device=dev)
         call("eqf_radius_graph_count", _P(pos), _P(mol_ptr), num_graphs, float(r), int(max_num_neighbors), _P(deg), st)
-        row_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        reuse = (into is not None and into.N == N and into.num_graphs == int(num_graphs) and into.src.device == dev
+                 and getattr(into, "_radius_static", False))
+        # (a candidate for in-place reuse gets the scan written straight into its row_ptr: if the edge count then differs the graph
+        # is abandoned by its owner anyway -- equiformer_amd/capture.py falls back to an eager step on a fresh graph)
+        row_ptr = into.row_ptr if reuse else torch.empty(N + 1, dtype=torch.int32, device=dev)
         call("eqf_exclusive_scan_i32", _P(deg), N, _P(row_ptr), _P(stats), st)
         E, max_mol_nodes = stats.tolist()  # the one host sync of graph construction (the reference syncs here as well)
-        if (into is not None and into.N == N and into.E == E and into.num_graphs == int(num_graphs)
-                and into.src.device == dev and getattr(into, "_radius_static", False)):
-            into.row_ptr.copy_(row_ptr)
+        if reuse and into.E != E:
+            row_ptr = row_ptr.clone()  # (the caller's tensors must not alias the abandoned graph's)
+            into._radius_static = False
+        if reuse and into.E == E:
             into.mol_ptr.copy_(mol_ptr)
             if into.batch.data_ptr() != b32.data_ptr():
                 into.batch.copy_(b32)
