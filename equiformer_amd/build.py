@@ -12,11 +12,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libequiformer_hip.so")
-SOURCES = ["gemm.hip", "gemmx.hip", "sfc.hip", "sfcx.hip", "sfcy.hip", "rowops.hip", "edge.hip", "graph.hip", "second.hip", "dpattn.hip", "optim.hip", "prof.hip"]
+SOURCES = ["gemm.hip", "gemmx.hip", "sfc.hip", "sfcx.hip", "sfcy.hip", "sfcw.hip", "rowops.hip", "edge.hip", "graph.hip", "second.hip", "dpattn.hip", "optim.hip", "prof.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 # per-source flags.  sfcx.hip issues bf16 MFMAs: no packed-FP32 VALU instruction may be generated beside them (the SLP
 # vectoriser is what turns neighbouring scalar fp32 operations into v_pk_*_f32)
-EXTRA_FLAGS = {"sfcx.hip": ["-fno-slp-vectorize"], "sfcy.hip": ["-fno-slp-vectorize"], "gemmx.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"sfcx.hip": ["-fno-slp-vectorize"], "sfcy.hip": ["-fno-slp-vectorize"], "sfcw.hip": ["-fno-slp-vectorize"], "gemmx.hip": ["-fno-slp-vectorize"]}
 
 
 def _code_only(text):

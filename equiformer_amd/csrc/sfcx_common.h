@@ -558,3 +558,7 @@ inline int plan_bwd(const SfcCommon& C, const eqf_dtp_paths* P, int mode, XBwdAr
 // csrc/sfcy.hip: the multi-wave forward (round 6).  EQF_E_UNSUPPORTED: shape outside its tables, nothing launched.
 int sfcy_fwd_launch(const sfc::SfcCommon* C, const eqf_dtp_paths* paths, int mode, int gate_on, int gS, int gG, float c_silu,
                     float c_sig, const float* bias0, const float* bias2, const void* packed, void* stream);
+// csrc/sfcw.hip: the multi-wave weight gradient (round 6).  EQF_E_UNSUPPORTED: shape outside its tables, nothing launched.
+int sfcw_wgrad_launch(const sfc::SfcCommon* C, const eqf_dtp_paths* paths, int mode, int gate_on, int gS, int gG, float c_silu,
+                      float c_sig, float* d_bias0, float* d_bias2, void* stream);
+void sfcw_dev_set(int key, int value);

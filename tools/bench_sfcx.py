@@ -21,6 +21,13 @@ dev = torch.device("cuda:0")
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
 L = _lib.load()
+for _a in sys.argv:  # --wgrad-variant=1 (one-wave kernel) / 2 (multi-wave, csrc/sfcw.hip); default 0 = the library's choice
+    if _a.startswith("--wgrad-variant="):
+        L.eqf_sfcx_dev_set(4, int(_a.split("=")[1]))
+    if _a.startswith("--wgrad-rounds="):
+        L.eqf_sfcx_dev_set(5, int(_a.split("=")[1]))
+    if _a.startswith("--wgrad-order="):
+        L.eqf_sfcx_dev_set(6, int(_a.split("=")[1]))
 
 
 def timeit(fn, n=30):
