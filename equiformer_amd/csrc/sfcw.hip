@@ -61,7 +61,7 @@ struct WArgs {
   int x_ld, m_ld, w_ld, E;
   const float *d1, *d2;
   int ld1, ld2;
-  int echunk, ntype;
+  int echunk, ntype, only_type;
   int plane_floats, wave_floats;  // LDS: [2 buffers of planes][per wave: coupling block, four transposition tiles]
   float *db, *db2;
   XGate gate;
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(64 * W_WAVES, 2) void sfcw_wgrad_kernel(const WArgs
   KERNARG_IN_PLACE(WArgs);
   int chunk, y;
   if (!order_xy(g.ord, blockIdx.x, chunk, y)) return;
+  if (g.only_type >= 0 && y != g.only_type) return;
   const WType T = g.type[y];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave >= T.nsl) return;  // (a terminated wave no longer counts at the workgroup's barriers)
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(64 * W_WAVES, 2) void sfcw_wgrad_kernel(const WArgs
 #define EQF_W_ROUNDS 3
 #endif
 static int g_w_rounds = 0;  // development (sfcw_dev_set 0): rounds of resident workgroups the chunk length is sized for
+static int g_w_only = -1;  // development (sfcw_dev_set 2): only the workgroups of this type (index after the cost sort) run
 static int g_w_order = 2;   // development (sfcw_dev_set 1): 0 heaviest-first in batches of 8 chunks per XCD, 1 chunk-major (XCD-aware), 2 type-major, heaviest first
 
 int plan_wgrad2(const SfcCommon& C, const eqf_dtp_paths* P, const XGate* gate, WArgs& A, int& nblk, size_t& lds, int npa) {
@@ -468,6 +470,32 @@ int plan_wgrad2(const SfcCommon& C, const eqf_dtp_paths* P, const XGate* gate, W
 void sfcw_dev_set(int key, int value) {
   if (key == 0) g_w_rounds = value;
   if (key == 1) g_w_order = value;
+  if (key == 2) g_w_only = value;
+}
+
+// Text dump of the launch plan for the CPU tests (eqf_sfcx_dev_plan kind 3): header, one line per workgroup type
+int sfcw_dev_plan(const sfc::SfcCommon* Cp, const eqf_dtp_paths* paths, int mode, char* buf, int buflen) {
+  static thread_local WArgs A;
+  int nblk = 0, n = 0;
+  size_t lds = 0;
+  const int npa = mode == 0 ? 2 : (mode == 1 ? 1 : 3);
+  const int rc = plan_wgrad2(*Cp, paths, nullptr, A, nblk, lds, npa);
+  if (rc) return rc;
+#define PUT(...)                                                          \
+  do {                                                                    \
+    n += snprintf(buf + n, n < buflen ? buflen - n : 0, __VA_ARGS__);     \
+    if (n >= buflen) return EQF_E_UNSUPPORTED;                            \
+  } while (0)
+  PUT("wgrad2 nblk %d lds %d echunk %d nx %d ny %d per_xcd %d mode %d\n", nblk, (int)lds, A.echunk, A.ord.nx, A.ord.ny, A.ord.per_xcd,
+      A.ord.mode);
+  for (int y = 0; y < A.ntype; ++y) {
+    const WType& Y = A.type[y];
+    PUT("type %d %d %d %d %d %d", Y.deg, A.deg[Y.deg].d3, Y.slab0, Y.nsl, Y.ct0, Y.ct);
+    for (int q = 0; q < Y.nsl; ++q) PUT(" %d:%d", A.slab[Y.slab0 + q].sid, A.slab[Y.slab0 + q].d1);
+    PUT("\n");
+  }
+#undef PUT
+  return n;
 }
 
 // Launch of the multi-wave weight gradient for the operator described by C (built by sfcx.hip's entry point); returns
@@ -485,6 +513,7 @@ int sfcw_wgrad_launch(const sfc::SfcCommon* Cp, const eqf_dtp_paths* paths, int 
   int rc = plan_wgrad2(C, paths, &XG, A, nblk, lds, npa);
   if (rc) return rc;
   A.db = d_bias0, A.db2 = d_bias2;
+  A.only_type = g_w_only;
   hipStream_t st = (hipStream_t)stream;
 #define WG_LAUNCH(M)                                                                                                 \
   do {                                                                                                               \

@@ -562,3 +562,4 @@ int sfcy_fwd_launch(const sfc::SfcCommon* C, const eqf_dtp_paths* paths, int mod
 int sfcw_wgrad_launch(const sfc::SfcCommon* C, const eqf_dtp_paths* paths, int mode, int gate_on, int gS, int gG, float c_silu,
                       float c_sig, float* d_bias0, float* d_bias2, void* stream);
 void sfcw_dev_set(int key, int value);
+int sfcw_dev_plan(const sfc::SfcCommon* C, const eqf_dtp_paths* paths, int mode, char* buf, int buflen);

@@ -445,6 +445,46 @@ def test_weight_gradient_replay_equals_the_definition(case):
         assert _rel(dW[l3], rW[l3]) < 1e-12, l3
 
 
+@pytest.mark.parametrize("case,E", [("qm9_sep_act", 25354), ("qm9_sep_value", 9000), ("oc20_l1", 100000), ("qm9_sep_act", 70)])
+def test_multi_wave_weight_gradient_plan_covers_every_slab_tile_and_edge_once(case, E):
+    """csrc/sfcw.hip (round 6): workgroup types = (output degree, group of <= 4 slabs, column group), heaviest first; workgroup
+    (chunk, type) works on the edges [chunk * echunk, +echunk).  Every (slab of the degree, 32-column tile) must be owned by exactly
+    one type, no wave may own more d_out tiles than the kernel has slots for ((tiles + 2) // 3), chunks are whole 32-edge blocks
+    and the grid enumerates every (chunk, type) once."""
+    irr, sh, out_irr, n2, _ = CASES[case]
+    table, lay = DtpTable(irr, sh, irr), RowLayout(out_irr)
+    spec = ops.SfcSpec(table, lay, n2=n2)
+    plan = _plan(3, table, lay, n2, E, 0)
+    hdr = dict(zip(plan[0][1::2], map(int, plan[0][2::2])))
+    types = [ln[1:] for ln in plan if ln[0] == "type"]
+    assert hdr["ny"] == len(types) and hdr["echunk"] % 32 == 0 and hdr["nx"] * hdr["echunk"] >= E > (hdr["nx"] - 1) * hdr["echunk"]
+    assert hdr["lds"] <= 80 * 1024
+    owned = {}
+    for t in types:
+        deg, d3, slab0, nsl, ct0, ct = map(int, t[:6])
+        slabs = [tuple(map(int, q.split(":"))) for q in t[6:]]
+        assert len(slabs) == nsl and 1 <= nsl <= 4 and 1 <= ct <= {1: 3, 3: 2, 5: 1}[d3]
+        assert -(-d3 * ct // nsl) <= (d3 * ct + 2) // 3
+        for sid, d1 in slabs:
+            for c in range(ct0, ct0 + ct):
+                assert (deg, sid, c) not in owned
+                owned[(deg, sid, c)] = 1
+    want = 0
+    for di, (l3, K, N1, ncat) in enumerate(spec.degs):
+        want += (K // 32) * (ncat // 32)
+        for sid in range(K // 32):
+            for c in range(ncat // 32):
+                assert (di, sid, c) in owned, (di, sid, c)
+    assert len(owned) == want
+    seen = set()
+    for b in range(hdr["nblk"]):
+        xy = _order_xy(b, hdr["nx"], hdr["ny"], hdr["per_xcd"], hdr["mode"])
+        if xy is not None:
+            assert xy not in seen
+            seen.add(xy)
+    assert len(seen) == hdr["nx"] * hdr["ny"]
+
+
 def test_l3_plans():
     """MD17 L_max = 3 (config #4): forward, weight gradient and -- since the output degrees are processed in chunks of m3 --
     the data gradient are planned (d1, d3 up to 7); the replays equal the definition."""

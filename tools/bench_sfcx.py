@@ -93,6 +93,11 @@ def run(name, irr, sh_irr, out_irr, n2, use_w, want_dM=False):
         for tag, fn in (("fwd", fx), ("bwd_weight", wx)):
             us = timeit(fn)
             print("%-10s mode %d %-10s %7.1f us  (%5.1f TFLOP/s)" % (name, mode, tag, us, flops / us / 1e6), flush=True)
+        if "--wtypes" in sys.argv:  # the multi-wave weight gradient with the workgroups of one type only (index after the cost sort)
+            for ty in range(24):
+                L.eqf_sfcx_dev_set(7, ty)
+                print("%-10s            wgrad workgroups of type %2d only: %7.1f us" % (name, ty, timeit(wx)), flush=True)
+            L.eqf_sfcx_dev_set(7, -1)
         if "--wclasses" in sys.argv:  # the weight-gradient launch with the items of one (input degree, output degree) class only
             for di in (1, 3, 5):
                 for do in (1, 3, 5):
