@@ -105,6 +105,19 @@ __device__ __forceinline__ void stage_m(float* __restrict__ Mt, const int MS, co
   }
 }
 
+// one wave per workgroup: LDS instructions of a wave execute in order, so write -> read of the wave's own tile needs no
+// s_barrier, only that the compiler keeps the order
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// WAVE = true (workgroups whose waves run DIFFERENT work side by side -- the path-split data gradient of round 6): the tile is
+// wave-private, ordering the wave's own LDS instructions is all the synchronisation it needs; false: the workgroup barrier.
+template <bool WAVE>
+__device__ __forceinline__ void tile_sync() {
+  if constexpr (WAVE) wave_lds_order();
+  else __syncthreads();
+}
 // A 32 rows x 32 floats tile between global memory and the layout of a 32x32 MFMA C fragment (lane (r, hi) holds, of row r,
 // the four 16-byte runs at columns 8 g4 + 4 hi), by way of a wave-private LDS tile: every global instruction then moves whole
 // 128-byte lines (8 rows per instruction) instead of 64 pieces of 32 bytes (a quarter of the address-unit work per byte;
@@ -126,12 +139,13 @@ __device__ __forceinline__ void tile_fetch(f32x4 (&t)[4], const float* __restric
   }
 }
 // row-major registers -> LDS tile -> fragment registers
+template <bool WAVE = false>
 __device__ __forceinline__ void tile_to_frag(float* __restrict__ T, const f32x4 (&t)[4], float (&v)[16], const int lane) {
   const int c = lane & 7, rr = lane >> 3, r = lane & 31, hi = lane >> 5;
-  __syncthreads();
+  tile_sync<WAVE>();
 #pragma unroll
   for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(T + ((rr + 8 * it) * XT_LD + 4 * c)) = t[it];
-  __syncthreads();
+  tile_sync<WAVE>();
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
     const f32x4 u = *reinterpret_cast<const f32x4*>(T + (r * XT_LD + 8 * g4 + 4 * hi));
@@ -140,14 +154,15 @@ __device__ __forceinline__ void tile_to_frag(float* __restrict__ T, const f32x4 
   }
 }
 // fragment registers -> LDS tile -> row-major stores of the rows e0 + row < E
+template <bool WAVE = false>
 __device__ __forceinline__ void tile_store(float* __restrict__ T, const float (&v)[16], float* __restrict__ base,
                                            const unsigned ld, const int e0, const int E, const int lane) {
   const int c = lane & 7, rr = lane >> 3, r = lane & 31, hi = lane >> 5;
-  __syncthreads();
+  tile_sync<WAVE>();
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4)
     *reinterpret_cast<f32x4*>(T + (r * XT_LD + 8 * g4 + 4 * hi)) = f32x4{v[4 * g4], v[4 * g4 + 1], v[4 * g4 + 2], v[4 * g4 + 3]};
-  __syncthreads();
+  tile_sync<WAVE>();
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = rr + 8 * it;
@@ -156,12 +171,6 @@ __device__ __forceinline__ void tile_store(float* __restrict__ T, const float (&
   }
 }
 
-// one wave per workgroup: LDS instructions of a wave execute in order, so write -> read of the wave's own tile needs no
-// s_barrier, only that the compiler keeps the order
-__device__ __forceinline__ void wave_lds_order() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 // 16 rows x 32 floats, row-major in memory (rows e_lo .. e_lo + 15, clamped to elast) -> lane (r, hi) gets column r of the rows
 // 8 hi .. 8 hi + 7: two 16-byte-per-lane loads of whole 128-byte lines and a wave-private LDS tile instead of eight 4-byte
 // loads that each touch two lines (weight gradient: both MFMA operands are "lane = column, 8 edges per lane")
@@ -312,6 +321,7 @@ struct XBwdArgs {
   const __bf16* packed;
   int ms;
   int only_d1;  // development switch: 0, or the only input degree (2 l + 1) whose items run
+  int psplit;   // small graphs (L_max <= 2): two waves per item, each runs every other path (sfcx_bwd_kernel)
   XGate gate;
   SfcOrder ord;  // nx = edge tiles, ny = groups of this launch
   struct Deg {

@@ -24,6 +24,11 @@ L = _lib.load()
 for _a in sys.argv:  # --wgrad-variant=1 (one-wave kernel) / 2 (multi-wave, csrc/sfcw.hip); default 0 = the library's choice
     if _a.startswith("--wgrad-variant="):
         L.eqf_sfcx_dev_set(4, int(_a.split("=")[1]))
+    if _a.startswith("--bwd-split-slots="):  # wave slots the path-split data gradient may take (0 = never split)
+        v = int(_a.split("=")[1])
+        L.eqf_sfcx_dev_set(9, 1 if v == 0 else 0)
+        if v:
+            L.eqf_sfcx_dev_set(10, v)
     if _a.startswith("--wgrad-rounds="):
         L.eqf_sfcx_dev_set(5, int(_a.split("=")[1]))
     if _a.startswith("--wgrad-order="):

@@ -26,7 +26,7 @@ d = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "pmc_dominant.json")
 PROF = {"sfc_fwd_kernel": "sfc_fwd", "sfc_bwd_kernel": "sfc_bwd_data", "sfc_wgrad_kernel": "sfc_wgrad",
         "sfcx_fwd_kernel": "sfcx_fwd", "sfcy_fwd_kernel": "sfcx_fwd",  # (the multi-wave forward of round 6 reports under the same timer)
-        "sfcx_bwd_kernel": "sfcx_bwd_data", "sfcx_wgrad_kernel": "sfcx_wgrad",
+        "sfcx_bwd_kernel": "sfcx_bwd_data", "sfcx_wgrad_kernel": "sfcx_wgrad", "sfcw_wgrad_kernel": "sfcx_wgrad",
         # the two kernels BASELINE.json's north_star names: per-destination softmax + scatter, widest radial-MLP layer
         "attn_fwd_half_kernel": "attn_fwd", "attn_fwd_kernel": "attn_fwd", "gemmx_rows_wide_kernel": "gemmx_rows_wide"}
 # average durations of the same kernels from the kernel trace of the SAME build (tools/gpu_profile.sh writes kernel_stats.csv
