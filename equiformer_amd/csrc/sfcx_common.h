@@ -373,7 +373,8 @@ struct XFwdArgs {
   const float *bias, *bias2;
   const __bf16* packed;
   int ms;  // row stride of the staged coupling block (odd)
-  int wave_lds;  // floats of LDS per wave (two waves per workgroup on small graphs: coupling block / partial-sum hand-over)
+  int wave_lds;  // floats of LDS per wave: its coupling block (up to four waves per workgroup on small graphs)
+  int red_off;   // float offset of the partial-sum hand-over area behind the waves' regions (small graphs)
   XGate gate;
   SfcOrder ord;  // nx = edge tiles, ny = (degree, column group) items
   struct Deg {

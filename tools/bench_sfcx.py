@@ -29,6 +29,8 @@ for _a in sys.argv:  # --wgrad-variant=1 (one-wave kernel) / 2 (multi-wave, csrc
         L.eqf_sfcx_dev_set(9, 1 if v == 0 else 0)
         if v:
             L.eqf_sfcx_dev_set(10, v)
+    if _a.startswith("--fwd-split="):  # at most this many waves per forward item on small graphs (1, 2, 4)
+        L.eqf_sfcx_dev_set(11, int(_a.split("=")[1]))
     if _a.startswith("--wgrad-rounds="):
         L.eqf_sfcx_dev_set(5, int(_a.split("=")[1]))
     if _a.startswith("--wgrad-order="):
