@@ -216,6 +216,40 @@ __device__ __forceinline__ void gx_mma(const __bf16* __restrict__ As, const __bf
   }
 }
 
+// Output tile of one wave (32 x 32 accumulator fragment: register q of lane (r, hi) = row (q & 3) + 8 (q >> 2) + 4 hi, column r)
+// -> memory as 16-byte stores of whole 128-byte lines, 16 rows at a time through a wave-private LDS tile: 4 store instructions per
+// tile instead of 16 that each write two half lines (round 6: the radial bank's widest layer is bound by its 681 MB of writes).
+// Needs 16-byte aligned rows (checked by the caller); bias already added.  rowptr(global row) -> first element of the row.
+constexpr int GX_ST_LD = 36;
+constexpr int GX_ST_FLOATS = 16 * GX_ST_LD;  // per wave
+template <typename RowPtr>
+__device__ __forceinline__ void gx_store_tile16(const f32x16& acc, float* __restrict__ T, const int row0, const int M, const int col0,
+                                                const int N, const bool accumulate, const int lane, RowPtr rowptr) {
+  const int r = lane & 31, hi = lane >> 5, c4 = 4 * (lane & 7), rr = lane >> 3;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) T[((q8 & 3) + 8 * (q8 >> 2) + 4 * hi) * GX_ST_LD + r] = acc[8 * half + q8];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int lr = rr + 8 * k, grow = row0 + 16 * half + lr;
+      f32x4 v = *reinterpret_cast<const f32x4*>(T + lr * GX_ST_LD + c4);
+      if (grow < M && col0 + c4 < N) {
+        float* const p = rowptr(grow) + (col0 + c4);
+        if (accumulate) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(p);
+          v[0] += o[0], v[1] += o[1], v[2] += o[2], v[3] += o[3];
+        }
+        *reinterpret_cast<f32x4*>(p) = v;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ rows kernels (kinds 0, 1)
 template <int MODE, int BKIND, bool VEC>
 __global__ __launch_bounds__(256) void gemmx_rows_kernel(const GXGroup g_byval) {
@@ -271,12 +305,25 @@ __global__ __launch_bounds__(256) void gemmx_rows_kernel(const GXGroup g_byval) 
   // epilogue: accumulator register q of lane (r, hi) = tile row (q & 3) + 8 (q >> 2) + 4 hi, column r
   const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
   const int col = n0 + wn0 + r;
-  if (col >= P.N) return;
-  const float bv = P.bias ? P.bias[col] : 0.f;
+  const float bv = (P.bias && col < P.N) ? P.bias[col] : 0.f;
   const bool flat_c = P.C.d == 1;
   const SmallDiv cdiv(P.C.d);
   float* const cbase = const_cast<float*>(P.C.base);
   const int rb = m0 + wm0 + 4 * hi;
+  static_assert(sizeof(As) >= 4 * GX_ST_FLOATS * sizeof(float), "the operand stages double as the store tiles");
+  if (((P.C.ld | P.C.inner | P.N) & 3) == 0 && (reinterpret_cast<size_t>(cbase) & 15) == 0) {  // uniform: 16-byte stores
+    // (the last barrier of the K loop is behind every wave: the operand stages are free)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] += bv;
+    gx_store_tile16(acc, reinterpret_cast<float*>(&As[0][0]) + wave * GX_ST_FLOATS, m0 + wm0, P.M, n0 + wn0, P.N, P.accumulate != 0,
+                    lane, [&](const int grow) {
+                      if (flat_c) return cbase + (long)grow * P.C.ld;
+                      const int qd = grow / P.C.d;
+                      return cbase + (long)qd * P.C.ld + (long)(grow - qd * P.C.d) * P.C.inner;
+                    });
+    return;
+  }
+  if (col >= P.N) return;
   long off0;
   int rem0 = 0;
   if (flat_c) {
@@ -354,6 +401,7 @@ __global__ __launch_bounds__(256) void gemmx_rows_wide_kernel(const GXGroup g_by
   if (m0 >= P.M) return;
   __shared__ __attribute__((aligned(16))) __bf16 As[NA * GW_ROW];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[NB * GW_ROW];
+  __shared__ __attribute__((aligned(16))) float St[4 * GX_ST_FLOATS];  // output tiles on their way to 16-byte stores
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
   const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
   LoaderWide<NA> la;
@@ -376,6 +424,7 @@ __global__ __launch_bounds__(256) void gemmx_rows_wide_kernel(const GXGroup g_by
     off0 = (long)qb * P.C.ld;
   }
   const int nkt = (P.K + 15) / 16;
+  const bool vec_c = ((P.C.ld | P.C.inner | P.N) & 3) == 0 && (reinterpret_cast<size_t>(cbase) & 15) == 0;  // uniform
   for (int n0 = 0; n0 < P.N; n0 += GX_T) {
     __syncthreads();  // the previous tile's fragments are read (and, first time round, As is complete after the next barrier)
     lb.commit(Bs);
@@ -396,7 +445,16 @@ __global__ __launch_bounds__(256) void gemmx_rows_wide_kernel(const GXGroup g_by
       }
     }
     const int col = n0 + wn0 + r;
-    if (col < P.N) {
+    if (vec_c) {
+      const float bv = (P.bias && col < P.N) ? P.bias[col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] += bv;
+      gx_store_tile16(acc, St + wave * GX_ST_FLOATS, m0 + wm0, P.M, n0 + wn0, P.N, P.accumulate != 0, lane, [&](const int grow) {
+        if (flat_c) return cbase + (long)grow * P.C.ld;
+        const int qd = grow / P.C.d;
+        return cbase + (long)qd * P.C.ld + (long)(grow - qd * P.C.d) * P.C.inner;
+      });
+    } else if (col < P.N) {
       const float bv = P.bias ? P.bias[col] : 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
