@@ -274,6 +274,9 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
  * elements, 16-byte aligned), in MFMA fragment order for the forward and for the data gradient; the other arguments
  * are those of eqf_sfc_fwd / _bwd_data / _bwd_weight.  Limits: per-edge tensors < 2^31 elements, degrees <= 3, row
  * strides that are multiples of four floats (EQF_E_UNSUPPORTED otherwise: use the eqf_sfc_* entry point of the same shape).
+ * Which kernel serves a call is the library's choice by shape and edge count (csrc/sfcy.hip / sfcw.hip: multi-wave forward and
+ * weight gradient of L_max <= 2 operators from 8 192 edges on; csrc/sfcx.hip: one-wave kernels otherwise, with items split over
+ * several waves on graphs too small to fill the machine); results differ only in fp32 summation order between them.
  * [ref: as eqf_sfc_fwd; the dtype policy replaces torch.cuda.amp.autocast of engine.py:58-66] */
 long eqf_sfcx_packed_numel(const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int mode);
 /* host only, no launch: bit mask of the split-precision launches that can serve this operator (1 forward, 2 data gradient,
