@@ -453,7 +453,9 @@ int plan_wgrad2(const SfcCommon& C, const eqf_dtp_paths* P, const XGate* gate, W
         cost[b] = cost[b - 1], cost[b - 1] = tc;
       }
   }
-  const int rounds = g_w_rounds > 0 ? g_w_rounds : EQF_W_ROUNDS;
+  // (three rounds at the bench size: 152 / 129 / 124 / 133 us for 1 / 2 / 3 / 4; two on graphs of 10-17 k edges: 66 / 60 / 79 us at
+  // 10 000, 106 / 89 / 101 at 17 000 -- profiles/r06/r06_ag_*)
+  const int rounds = g_w_rounds > 0 ? g_w_rounds : (C.E >= 22000 ? EQF_W_ROUNDS : 2);
   int z = eqf_cdiv(rounds * 512, ntype);
   int echunk = eqf_cdiv(C.E, z);
   echunk = ((echunk + 31) / 32) * 32;

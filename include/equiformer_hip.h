@@ -275,7 +275,7 @@ int eqf_sfc_bwd_weight(const float* x, const float* coupling, const float* w, co
  * are those of eqf_sfc_fwd / _bwd_data / _bwd_weight.  Limits: per-edge tensors < 2^31 elements, degrees <= 3, row
  * strides that are multiples of four floats (EQF_E_UNSUPPORTED otherwise: use the eqf_sfc_* entry point of the same shape).
  * Which kernel serves a call is the library's choice by shape and edge count (csrc/sfcy.hip / sfcw.hip: multi-wave forward and
- * weight gradient of L_max <= 2 operators from 1 500-4 000 / 14 000-20 000 edges on; csrc/sfcx.hip: one-wave kernels otherwise, with items split over
+ * weight gradient of L_max <= 2 operators from 1 500-4 000 / 9 000-20 000 edges on; csrc/sfcx.hip: one-wave kernels otherwise, with items split over
  * several waves on graphs too small to fill the machine); results differ only in fp32 summation order between them.
  * [ref: as eqf_sfc_fwd; the dtype policy replaces torch.cuda.amp.autocast of engine.py:58-66] */
 long eqf_sfcx_packed_numel(const eqf_dtp_paths* paths, const eqf_irreps* out1_irreps, int n2, int mode);
